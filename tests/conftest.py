@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| per tensor: the 1e-4 bar of BASELINE.json is stated on this measure."""
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        z = np.load(os.path.join(GOLDEN, name))
+        return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k] for k in z.files}
+    return load
+
+
+@pytest.fixture(scope="session")
+def synth_weights():
+    from style_transfer_based_holographic_imaging_amd import synth
+    return synth.synthetic_state_dicts(0)
+
+
+@pytest.fixture(scope="session")
+def mnist_style():
+    return torch.load(os.path.join(REPO, "style_representation", "MNIST", "style_vector.pt"),
+                      map_location="cpu").float()
+
+
+def load_test_data(i, kind):
+    return torch.load(os.path.join(REPO, "test_data", f"test_{kind}_{i}.pt"), map_location="cpu")

@@ -1,0 +1,144 @@
+"""Pins oracle/holo_oracle.py: (1) against the reference's own known-answer data in test_data/,
+(2) against golden vectors produced by the reference itself (tests/golden/make_golden.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_test_data, rel_err
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import holo_oracle as orc  # noqa: E402
+
+HP = orc.HoloParams()
+
+
+@pytest.mark.parametrize("i", range(20))
+def test_kat_hologram_is_propagated_gt_field(i):
+    """content_holo == |ASM(gt_amp * exp(i gt_phase), d_content mm)|^2."""
+    holo = load_test_data(i, "content_holo")
+    gt_a = load_test_data(i, "gt_amplitude")
+    gt_p = load_test_data(i, "gt_phase")
+    d = load_test_data(i, "distance_content")
+    out = orc.holo_generator(HP, gt_a, gt_p, d)
+    assert rel_err(out, holo) < 2e-6
+
+
+def test_net_outputs_file0(golden, synth_weights, mnist_style):
+    g = golden("golden_net_s128.npz")
+    vgg, dec, dist = synth_weights
+    content = torch.sqrt(load_test_data(0, "content_holo")).float()
+    d_style = load_test_data(0, "distance_style").float()
+    with torch.no_grad():
+        amp, ph, d, a_f, p_f, fld = orc.full_step(content, mnist_style, d_style, vgg, dec, dist)
+    assert rel_err(amp, g["amp"]) < 2e-5
+    assert rel_err(ph, g["ph"]) < 2e-5
+    assert rel_err(d.view(-1), g["dist"].view(-1)) < 2e-5
+    assert rel_err(a_f, g["amp_foc"]) < 2e-5
+    ref = torch.complex(g["field_re"], g["field_im"])
+    assert rel_err(torch.view_as_real(fld.to(torch.complex64)), torch.view_as_real(ref)) < 2e-5
+
+
+@pytest.mark.parametrize("i", [3, 11, 19])
+def test_net_checksums_other_files(i, golden, synth_weights, mnist_style):
+    g = golden("golden_net_sums.npz")
+    vgg, dec, dist = synth_weights
+    content = torch.sqrt(load_test_data(i, "content_holo")).float()
+    d_style = load_test_data(i, "distance_style").float()
+    with torch.no_grad():
+        amp, ph, d, a_f, p_f, fld = orc.full_step(content, mnist_style, d_style, vgg, dec, dist)
+    outs = dict(amp=amp, ph=ph, amp_foc=a_f, field_re=fld.real.float(), field_im=fld.imag.float())
+    for k, v in outs.items():
+        stats = g[f"f{i}_{k}_stats"]
+        vd = v.double()
+        got = np.array([vd.mean().item(), vd.norm().item(), vd.abs().max().item()])
+        assert np.allclose(got, stats, rtol=2e-5, atol=2e-5 * abs(stats[2])), (k, got, stats)
+        sub = v[..., :: v.shape[-2] // 16, :: v.shape[-1] // 16][..., :16, :16]
+        assert rel_err(sub, g[f"f{i}_{k}_sub"]) < 5e-5
+    assert rel_err(d.view(-1), torch.as_tensor(g[f"f{i}_dist"]).view(-1)) < 2e-5
+
+
+def test_small_case_intermediates(golden, synth_weights, mnist_style):
+    g = golden("golden_small.npz")
+    vgg, dec, dist = synth_weights
+    with torch.no_grad():
+        holo = orc.holo_generator(HP, torch.full_like(g["phase_obj"], 0.6), g["phase_obj"], g["d_c"])
+        assert rel_err(holo, g["holo"]) < 2e-6
+        feats = orc.encode_with_intermediate(g["content"], vgg)
+        for k, f in zip(("enc1", "enc2", "enc3", "enc4"), feats):
+            assert rel_err(f, g[k]) < 1e-5, k
+        mean, std = orc.calc_mean_std(feats[-1])
+        assert rel_err(mean, g["mean"]) < 1e-5 and rel_err(std, g["std"]) < 1e-5
+        t = orc.adain_with_style_vector(feats[-1], mnist_style, 1.0)
+        assert rel_err(t, g["t"]) < 1e-5
+        out, stages = orc.decoder_forward(g["t"], dec, return_stages=True)
+        assert rel_err(stages[2], g["dec7"]) < 1e-5
+        assert rel_err(stages[7], g["dec21"]) < 1e-5
+        assert rel_err(stages[10], g["dec29"]) < 1e-5
+        assert rel_err(out, g["g_t"]) < 1e-5
+        assert rel_err(orc.distance_head(g["mean"], g["std"], dist), g["dist"]) < 1e-5
+        ad = orc.adaptive_instance_normalization(g["enc4"], g["enc4"].flip(0))
+        assert rel_err(ad, g["adain_img"]) < 1e-5
+
+
+def test_edge_cases(golden, synth_weights, mnist_style):
+    g = golden("golden_edges.npz")
+    s = golden("golden_small.npz")
+    vgg, dec, dist = synth_weights
+    c32 = s["content"]
+    with torch.no_grad():
+        a1, p1, d1 = orc.net_field_retrieval(c32[:1], mnist_style, vgg, dec, dist, 1.0, True)
+        assert rel_err(a1, g["b1_amp"]) < 2e-5 and rel_err(p1, g["b1_ph"]) < 2e-5
+        assert rel_err(d1, g["b1_dist"]) < 2e-5
+        am, pm, dm = orc.net_field_retrieval(c32, g["multi_style"], vgg, dec, dist, 1.0, True)
+        assert rel_err(am, g["multi_amp"]) < 2e-5 and rel_err(pm, g["multi_ph"]) < 2e-5
+        assert rel_err(dm, g["multi_dist"]) < 2e-5
+        for al, tag in ((0.0, "a0"), (0.5, "a05")):
+            aa, pa = orc.net_field_retrieval(c32, mnist_style, vgg, dec, None, al)
+            assert rel_err(aa, g[f"{tag}_amp"]) < 2e-5 and rel_err(pa, g[f"{tag}_ph"]) < 2e-5
+        f36 = orc.encode_with_intermediate(g["odd_content"], vgg)
+        assert f36[2].shape == g["odd_enc3"].shape and f36[3].shape == g["odd_enc4"].shape
+        assert rel_err(f36[3], g["odd_enc4"]) < 1e-5
+        a36, p36, d36 = orc.net_field_retrieval(g["odd_content"], mnist_style, vgg, dec, dist, 1.0, True)
+        assert a36.shape == g["odd_amp"].shape == (2, 1, 40, 40)
+        assert rel_err(a36, g["odd_amp"]) < 2e-5 and rel_err(p36, g["odd_ph"]) < 2e-5
+        for name in ("polystyrene_bead", "red_blood_cell"):
+            sv = torch.load(os.path.join(REPO, "style_representation", name, "style_vector.pt"),
+                            map_location="cpu").float()
+            a_s, p_s, d_s = orc.net_field_retrieval(c32, sv, vgg, dec, dist, 1.0, True)
+            assert rel_err(a_s, g[f"{name}_amp"]) < 2e-5 and rel_err(p_s, g[f"{name}_ph"]) < 2e-5
+        assert rel_err(orc.distance_head(g["dh_mean"], g["dh_std"], dist), g["dh_out"]) < 1e-5
+        # batch-1 result equals row 0 of the batch result (net.py:255-256 repeats the row)
+        d_all = orc.distance_head(g["dh_mean"], g["dh_std"], dist)
+        d_one = orc.distance_head(g["dh_mean"][:1], g["dh_std"][:1], dist)
+        assert abs(float(d_all[0] - d_one[0])) < 1e-6
+
+
+@pytest.mark.parametrize("s", [16, 64])
+def test_asm_modes(s, golden):
+    g = golden("golden_asm.npz")
+    amp, ph, d = g[f"s{s}_amp_in"], g[f"s{s}_ph_in"], g[f"s{s}_d_mm"]
+    fld = orc.holo_generator(HP, amp, ph, d, complex_number=True)
+    ref = torch.complex(g[f"s{s}_field_re"], g[f"s{s}_field_im"])
+    assert fld.dtype == torch.complex128
+    assert rel_err(torch.view_as_real(fld.to(torch.complex64)), torch.view_as_real(ref)) < 2e-6
+    a_o, p_o = orc.holo_generator(HP, amp, ph, d, return_field=True)
+    assert rel_err(a_o, g[f"s{s}_amp"]) < 2e-6
+    assert rel_err(orc.holo_generator(HP, amp, ph, d), g[f"s{s}_intensity"]) < 2e-6
+    o_low = amp * torch.exp(1j * ph)
+    nopad = orc.asm(o_low, HP.wavelength, d * 1e-3, HP.pixel_size, zero_padding=False)
+    ref = torch.complex(g[f"s{s}_nopad_re"], g[f"s{s}_nopad_im"])
+    assert rel_err(torch.view_as_real(nopad.to(torch.complex64)), torch.view_as_real(ref)) < 2e-6
+    scal = orc.asm(o_low, HP.wavelength, 3.0e-4, HP.pixel_size, zero_padding=True)
+    ref = torch.complex(g[f"s{s}_scalar_re"], g[f"s{s}_scalar_im"])
+    assert rel_err(torch.view_as_real(scal.to(torch.complex64)), torch.view_as_real(ref)) < 2e-6
+
+
+def test_asm_two_channel_field(golden):
+    g = golden("golden_asm.npz")
+    o2 = torch.complex(g["c2_in_re"], g["c2_in_im"])
+    r2 = orc.asm(o2, HP.wavelength, torch.tensor([1e-4, -3e-4]).view(-1, 1, 1, 1), HP.pixel_size, True)
+    ref = torch.complex(g["c2_re"], g["c2_im"])
+    assert rel_err(torch.view_as_real(r2.to(torch.complex64)), torch.view_as_real(ref)) < 2e-6

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""holograms/s of the field-retrieval hot path on MI355X (BASELINE.json metric).
+
+One step = one pass of the path over one batch of synthetic holograms already resident in HBM:
+  encoder -> AdaIN (stored style) -> decoder -> distance head  (utils.functions.field_retrieval)
+  -> angular-spectrum back-propagation to focus (Holo_Generator(..., return_field=True)),
+i.e. test_field_retrieval_mnist.py:125-126 of the reference without the host-side unwrap.
+Default workload = BASELINE.json configs[1]: batch 64 per GPU, 256x256, fp32.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; every rank runs its own batch (weak scaling, no data-path collective)
+and the packed outputs are gathered to rank 0 with one RCCL gather per step, inside the timed region.
+Rank 0 prints one JSON line.  `roofline` is the fp32-MFMA convolution kernel (the dominant kernel),
+`roofline_propagator` the HBM-bound angular-spectrum propagator; both from HIP events recorded on the
+launch stream during the timed steps.  `cpu_baseline` times the CPU oracle (a port of the reference's
+torch-CPU path; the reference itself cannot travel to the GPU box) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+FLOP_PER_PIXEL = 1136262       # conv stack per input pixel (+5.24 MFLOP distance head)
+
+
+def build_network(device, seed=0):
+    import copy
+    import torch.nn as nn
+    import net
+    from style_transfer_based_holographic_imaging_amd import synth
+    vgg_sd, dec_sd, dist_sd = synth.synthetic_state_dicts(seed, full_vgg=True)
+    vgg = copy.deepcopy(net.vgg)
+    vgg.load_state_dict(vgg_sd)
+    dec = copy.deepcopy(net.decoder)
+    dec.load_state_dict(dec_sd)
+    dg = net.Distance_G()
+    dg.load_state_dict(dist_sd)
+    network = net.Net(nn.Sequential(*list(vgg.children())[:31]), dec, None, dg).eval().to(device)
+    return network, (vgg_sd, dec_sd, dist_sd)
+
+
+def cpu_baseline(size, sds, style, sample, seed):
+    """The oracle timed on the host cores, on `sample` holograms of the same workload."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import holo_oracle as orc
+    from style_transfer_based_holographic_imaging_amd import synth
+    hp = orc.HoloParams()
+    ph = synth.synthetic_phase_objects(sample, size, seed=seed)
+    d_c = synth.synthetic_distances(sample, seed=seed)
+    d_s = torch.full((sample, 1, 1, 1), 0.2)
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        content = torch.sqrt(orc.holo_generator(hp, torch.full_like(ph, 0.6), ph, d_c)).float()
+        orc.full_step(content, style, d_s, *sds, hp)  # warm-up
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orc.full_step(content, style, d_s, *sds, hp)
+            times.append(time.perf_counter() - t0)
+    best = sorted(times)[1]
+    return {"value": round(sample / best, 3), "unit": "holograms/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} holograms {size}x{size}, oracle/holo_oracle.py full_step, median of 3 after 1 warm-up, "
+                      f"torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="holograms per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=4, help="holograms in the CPU baseline (0 = skip)")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
+    args = ap.parse_args()
+
+    from style_transfer_based_holographic_imaging_amd import ops, shard, synth
+    rank, world, local = shard.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    from utils.Forward_model import Holo_Generator
+    from utils.functions import field_retrieval
+
+    network, sds = build_network(dev)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from holo_oracle import HoloParams
+    model_forward = Holo_Generator(HoloParams())
+    style_cpu = torch.load(os.path.join(REPO, "style_representation", "MNIST", "style_vector.pt"), map_location="cpu").float()
+    style = style_cpu.to(dev)
+
+    # synthetic input, SURVEY.md §8d config 2: phase objects -> holograms by forward propagation (on the GPU)
+    b, s = args.batch, args.size
+    seed = 1234 + rank
+    ph = synth.synthetic_phase_objects(b, s, seed=seed).to(dev)
+    d_content = synth.synthetic_distances(b, seed=seed).to(dev)
+    d_style = torch.full((b, 1, 1, 1), 0.2, device=dev)
+    with torch.no_grad():
+        content = torch.sqrt(model_forward(torch.full_like(ph, 0.6), ph, d_content)).contiguous()
+    del ph
+
+    def step():
+        with torch.no_grad():
+            amp, p, d = field_retrieval(network, content, style, 1.0, True)
+            a_f, p_f = model_forward(amp, p * 1.0, -d_style, return_field=True, unwrap=False)
+            if world > 1:
+                shard.gather_to_root(shard.pack_outputs(amp, p, a_f, p_f, d))
+        return amp, p, d, a_f, p_f
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timer = None if args.no_events else ops.KernelTimer()
+    t0 = time.perf_counter()
+    if timer is not None:
+        with timer:
+            for _ in range(args.steps):
+                step()
+    else:
+        for _ in range(args.steps):
+            step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total = b * world * args.steps
+        out = {
+            "metric": "holograms/sec (256x256 complex field retrieval)" if s == 256 else f"holograms/sec ({s}x{s} complex field retrieval)",
+            "value": round(total / elapsed, 2), "unit": "holograms/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: batch {b}/GPU synthetic {s}x{s} holograms, fp32, VGG-AdaIN-decoder + "
+                                   f"distance head + angular-spectrum back-propagation (P={2 * s}), seeded He-normal weights",
+                       "batch_per_gpu": b, "size": s, "parallelism": f"batch-sharded x{world}, one RCCL gather per step"},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            conv = [summ[k] for k in ("holo_conv3x3_f32", "holo_convt2x2_f32") if k in summ]
+            if conv:
+                fl = sum(r["flops"] for r in conv)
+                ms = sum(r["ms"] for r in conv)
+                calls = sum(r["calls"] for r in conv)
+                ach = fl / (ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                   "kernel": "conv_mfma_f32_kernel (3x3 + transposed, all layers)",
+                                   "launches_per_step": calls // args.steps, "avg_launch_ms": round(ms / calls, 4),
+                                   "gflop_per_launch": round(fl / calls / 1e9, 3)}
+            if "holo_asm_propagate" in summ:
+                r = summ["holo_asm_propagate"]
+                gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                out["roofline_propagator"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                              "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                              "kernel": "asm_rows_fwd + asm_cols + asm_rows_inv (80*S^2 B per field)",
+                                              "avg_call_ms": round(r["ms"] / r["calls"], 4)}
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(summ.items())}
+            out["conv_stack_tflops_overall"] = round(FLOP_PER_PIXEL * s * s * b * args.steps / 1e12 /
+                                                     (sum(v["ms"] for k, v in summ.items() if "conv" in k) * 1e-3), 2)
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(s, sds, style_cpu, args.cpu_sample, seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

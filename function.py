@@ -1,0 +1,23 @@
+"""Drop-in for the reference's ``function.py`` (feature statistics and AdaIN) on HIP kernels.
+
+``calc_mean_std`` (function.py:4-12) and ``adaptive_instance_normalization`` (function.py:15-23)
+keep their signatures; inputs are logical NCHW tensors on a ROCm device.  ``coral`` and friends are
+imported-but-unused in the reference and are not provided.
+"""
+from style_transfer_based_holographic_imaging_amd import ops
+
+
+def calc_mean_std(feat, eps=1e-5):
+    size = feat.size()
+    assert (len(size) == 4)
+    n, c = size[:2]
+    mean, std = ops.channel_mean_std(ops.to_nhwc(feat), eps)
+    return mean.view(n, c, 1, 1), std.view(n, c, 1, 1)
+
+
+def adaptive_instance_normalization(content_feat, style_feat):
+    assert (content_feat.size()[:2] == style_feat.size()[:2])
+    x = ops.to_nhwc(content_feat)
+    s_mean, s_std = ops.channel_mean_std(ops.to_nhwc(style_feat))
+    c_mean, c_std = ops.channel_mean_std(x)
+    return ops.as_nchw_view(ops.adain_apply(x, c_mean, c_std, s_mean, s_std, 1.0))

@@ -1,0 +1,142 @@
+/*
+ * holo_hip.h — C-ABI of the MI355X (gfx950) holographic field-retrieval hot path.
+ *
+ * The reference (csleemooo/style_transfer_based_holographic_imaging) is pure Python on torch
+ * `aten::` ops: it has no FFI.  Each entry point below therefore replaces the aten op sequence
+ * of one reference function; the reference-side binding (a ctypes stub) is shown in
+ * INTEGRATION.md.  Plain pointers, sizes and a hipStream_t only — no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the library never allocates,
+ *     never synchronises and never copies to the host: callers own all buffers (outputs and
+ *     workspace included) and the stream.  `stream` is a hipStream_t passed as void*.
+ *   - activations inside the network are NHWC fp32 ("channels last": pixel-major, channel
+ *     contiguous); network inputs/outputs are the reference's NCHW planes.
+ *   - return value 0 = launched; non-zero = rejected before any launch (bad shape/argument or
+ *     a HIP launch error), with the reason available from holo_last_error().
+ *   - thread-safety: entry points are re-entrant; holo_last_error() is per thread.
+ */
+#ifndef HOLO_HIP_H
+#define HOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOLO_ABI_VERSION 1
+
+/* error codes */
+#define HOLO_OK 0
+#define HOLO_ERR_ARG 1        /* bad pointer / shape / mode */
+#define HOLO_ERR_UNSUPPORTED 2 /* valid request the kernels do not cover (e.g. non power-of-two FFT side) */
+#define HOLO_ERR_WORKSPACE 3  /* workspace too small */
+#define HOLO_ERR_LAUNCH 4     /* hipGetLastError() after a launch */
+
+int holo_abi_version(void);
+const char* holo_last_error(void);
+/* name of the device code object's target ("gfx950"); fails the load on any other build */
+const char* holo_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight packing (done once per module; reference keeps OIHW / IOHW tensors, net.py:33-130)
+ * ---------------------------------------------------------------------------------------- */
+/* Conv2d weight (Cout,Cin,3,3) -> [tap=ky*3+kx][Cin/16][Cout][16] fp32, Cin % 16 == 0 */
+int holo_pack_conv3x3_weight_f32(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
+size_t holo_conv3x3_packed_elems(int cout, int cin);
+/* ConvTranspose2d weight (Cin,Cout,2,2) -> [Cin/16][q=dy*2+dx][Cout][16] fp32, Cin % 16 == 0 */
+int holo_pack_convt2x2_weight_f32(const float* w_iohw, float* w_packed, int cin, int cout, void* stream);
+size_t holo_convt2x2_packed_elems(int cin, int cout);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder / decoder convolutions
+ * ---------------------------------------------------------------------------------------- */
+/* vgg[0:4]  (net.py:77-80): Conv2d(1,3,1x1) -> ReflectionPad2d(1) -> Conv2d(3,64,3x3) -> ReLU.
+ * x: (B,1,H,W) plane(s), contiguous;  w0,b0: the 1x1 conv (3 + 3 floats);
+ * w1: the 3x3 conv weight in its native (64,3,3,3) OIHW order; b1: 64;  y: NHWC (B,H,W,64). */
+int holo_conv_first_f32(const float* x, const float* w0, const float* b0, const float* w1,
+                        const float* b1, float* y_nhwc, int batch, int h, int w, void* stream);
+
+/* ReflectionPad2d(1) -> Conv2d(Cin,Cout,3x3) -> [ReLU] -> [MaxPool2d(2,2,ceil_mode=True)]
+ * (every "c3" layer of net.py:33-107).  x: NHWC (B,H,W,Cin); w_packed from
+ * holo_pack_conv3x3_weight_f32; y: NHWC (B,H,W,Cout) or (B,ceil(H/2),ceil(W/2),Cout) with pool.
+ * Requires H,W >= 2, Cin % 16 == 0, Cout % 64 == 0.  fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+int holo_conv3x3_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc,
+                     int batch, int h, int w, int cin, int cout, int relu, int pool, void* stream);
+
+/* ConvTranspose2d(Cin,Cout,k=2,s=2) -> [ReLU] (net.py:40,55,64).  x: NHWC (B,H,W,Cin);
+ * y: NHWC (B,2H,2W,Cout).  Cin % 16 == 0, Cout % 64 == 0. */
+int holo_convt2x2_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc,
+                      int batch, int h, int w, int cin, int cout, int relu, void* stream);
+
+/* decoder[36:38] (net.py:72-73): ReflectionPad2d(1) -> Conv2d(64,2,3x3), no activation.
+ * x: NHWC (B,H,W,64); w: native (2,64,3,3) OIHW; y: NCHW (B,2,H,W): plane 0 amplitude,
+ * plane 1 phase (net.py:250-251). */
+int holo_conv_last_f32(const float* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
+                       int batch, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Feature statistics and AdaIN (function.py:4-23, net.py:235-246)
+ * ---------------------------------------------------------------------------------------- */
+/* calc_mean_std: per (n,c) mean and sqrt(unbiased_var + eps) over HW.  x: NHWC (B,HW,C);
+ * mean,std: (B,C).  C % 4 == 0, HW >= 2. */
+int holo_channel_mean_std_f32(const float* x_nhwc, float* mean, float* std, int batch, int hw,
+                              int c, float eps, void* stream);
+/* t = (x-mean)/std*style_std + style_mean ; y = alpha*t + (1-alpha)*x   (net.py:241-246).
+ * style_mean/style_std: (B or 1, C) with `style_batch_stride` floats between samples
+ * (0 = one style broadcast over the batch: the single-style method, net.py:237-238). */
+int holo_adain_apply_f32(const float* x_nhwc, const float* mean, const float* std,
+                         const float* style_mean, const float* style_std, long style_batch_stride,
+                         float alpha, float* y_nhwc, int batch, int hw, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Distance head (net.py:288-308)
+ * ---------------------------------------------------------------------------------------- */
+/* y[b][n] = bias[n] + sum_k x[b][k]*w[n][k]   (nn.Linear; w is (N,K) row-major) */
+int holo_linear_f32(const float* x, const float* w, const float* bias, float* y, int batch, int k,
+                    int n, void* stream);
+/* InstanceNorm1d on a (B,N) input = per-row (x-mean)/sqrt(biased_var+eps), then ReLU */
+int holo_rownorm_relu_f32(const float* x, float* y, int batch, int n, float eps, void* stream);
+/* y = sigmoid(bias + x . w) for the final Linear(512,1) */
+int holo_linear1_sigmoid_f32(const float* x, const float* w, const float* bias, float* y, int batch,
+                             int k, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Angular-spectrum propagation (utils/Angular_Spectrum_Method.py:7-53 + the field packing and
+ * abs/angle/intensity epilogues of utils/Forward_model.py:22-39)
+ * ---------------------------------------------------------------------------------------- */
+#define HOLO_ASM_IN_AMP_PHASE 0 /* in0 = amplitude planes, in1 = phase planes (fp32); O = a*exp(i*phase_scale*p) */
+#define HOLO_ASM_IN_COMPLEX 1   /* in0 = interleaved complex64 fields, in1 ignored */
+#define HOLO_ASM_OUT_AMP_PHASE 0 /* out0 = |H|, out1 = angle(H)   (Forward_model.py:28-29) */
+#define HOLO_ASM_OUT_INTENSITY 1 /* out0 = |H|^2                  (Forward_model.py:39) */
+#define HOLO_ASM_OUT_COMPLEX 2   /* out0 = interleaved complex64   (Forward_model.py:36-37) */
+
+/* bytes of scratch holo_asm_propagate needs (two S x P complex64 slabs per field / output) */
+size_t holo_asm_workspace_bytes(int n_fields, int n_dist, int s, int zero_padding);
+
+/* Propagates n_fields square S x S fields, each to n_dist distances (output field index =
+ * field*n_dist + dist).  phase_const[field*n_dist+dist] is the float64 constant c of
+ * theta = c * sqrt(max(0, 1 - l^2 (fx^2+fy^2))) / l, i.e. 2*pi*d with the reference's rounding
+ * (Angular_Spectrum_Method.py:29) — computed by the caller.
+ * in*_stride / out*_stride: elements (floats, or complex64 for the complex modes) between
+ * consecutive fields, so strided views such as g_t[:, :1] (net.py:250-251) need no copy.
+ * zero_padding != 0: replicate-pad to P = 2S (Angular_Spectrum_Method.py:11-14); else P = S.
+ * P must be a power of two, 8 <= P <= 2048. */
+int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_stride, long in1_stride,
+                       void* out0, void* out1, int out_mode, long out0_stride, long out1_stride,
+                       const double* phase_const, int n_fields, int n_dist, int s, int zero_padding,
+                       double wavelength, double pixel_size, float phase_scale,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout helpers
+ * ---------------------------------------------------------------------------------------- */
+int holo_nhwc_to_nchw_f32(const float* x, float* y, int batch, int hw, int c, void* stream);
+int holo_nchw_to_nhwc_f32(const float* x, float* y, int batch, int hw, int c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOLO_HIP_H */

@@ -1,0 +1,155 @@
+"""Drop-in for the reference's ``net.py`` on the inference path, running on MI355X HIP kernels.
+
+Same public surface as ``/root/reference/net.py``: module-level ``vgg`` (53 children,
+net.py:76-130) and ``decoder`` (38 children, net.py:33-74) with the reference's state-dict keys,
+``Net(encoder, decoder, decoder_ph=None, distance_g=None)`` (net.py:133-260) and ``Distance_G()``
+(net.py:266-327).  The children are parameter holders; the arithmetic is the fused plan of
+``style_transfer_based_holographic_imaging_amd.engine`` (NHWC fp32 MFMA convolutions, fused
+ReLU/pool epilogues).  Training-only pieces (``Net.forward`` losses, ``Discriminator``) are out of
+scope.  Tensors must live on a ROCm device: there is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from function import calc_mean_std
+from style_transfer_based_holographic_imaging_amd import ops
+from style_transfer_based_holographic_imaging_amd.engine import HoloSequential
+
+
+def _pad():
+    return nn.ReflectionPad2d((1, 1, 1, 1))
+
+
+def _conv_block(cin, cout, relu=True):
+    layers = [_pad(), nn.Conv2d(cin, cout, (3, 3))]
+    if relu:
+        layers.append(nn.ReLU())
+    return layers
+
+
+def _up(c):
+    return [nn.ConvTranspose2d(c, c, 2, stride=2, padding=0), nn.ReLU()]
+
+
+def _pool():
+    return nn.MaxPool2d((2, 2), (2, 2), (0, 0), ceil_mode=True)
+
+
+def _build_decoder():
+    # 512 ->512 ->256 ^ 256 x3 ->128 ^ 128 ->64 ^ 64 x2 -> 2   (^ = ConvTranspose2d k2 s2)
+    spec = [(512, 512), (512, 256), "up256", (256, 256), (256, 256), (256, 256), (256, 128), "up128",
+            (128, 128), (128, 64), "up64", (64, 64), (64, 64)]
+    layers = []
+    for item in spec:
+        layers += _up(int(item[2:])) if isinstance(item, str) else _conv_block(*item)
+    layers += _conv_block(64, 2, relu=False)
+    return HoloSequential(*layers)
+
+
+def _build_vgg():
+    # VGG-19 with a 1->3 1x1 pre-conv; "P" = 2x2 max-pool with ceil_mode
+    widths = [(3, 64), (64, 64), "P", (64, 128), (128, 128), "P", (128, 256), (256, 256), (256, 256), (256, 256),
+              "P", (256, 512), (512, 512), (512, 512), (512, 512), "P", (512, 512), (512, 512), (512, 512),
+              (512, 512)]
+    layers = [nn.Conv2d(1, 3, (1, 1))]
+    for item in widths:
+        layers += [_pool()] if item == "P" else _conv_block(*item)
+    return HoloSequential(*layers)
+
+
+decoder = _build_decoder()
+vgg = _build_vgg()
+
+
+class Net(nn.Module):
+    """net.py:133-260.  ``encoder`` is an ``nn.Sequential`` (e.g. ``vgg`` truncated to 31 children)."""
+
+    def __init__(self, encoder, decoder, decoder_ph=None, distance_g=None):
+        super().__init__()
+        if isinstance(encoder, str):
+            raise TypeError("Net(encoder=<path>) relies on an Encoder class the reference never defines; "
+                            "pass the nn.Sequential encoder instead")
+        enc_layers = list(encoder.children())
+        bounds = [0, 4, 11, 18, 31] + ([44] if len(enc_layers) > 35 else [])
+        self.n_layer = len(bounds) - 1
+        for k in range(self.n_layer):
+            setattr(self, f"enc_{k + 1}", HoloSequential(*enc_layers[bounds[k]:bounds[k + 1]]))
+        self.decoder = decoder if isinstance(decoder, HoloSequential) else HoloSequential(*decoder.children())
+        self.decoder_ph = decoder_ph
+        self.distance_g = distance_g
+        self.mse_loss = nn.MSELoss()
+        for k in range(self.n_layer):
+            for param in getattr(self, f"enc_{k + 1}").parameters():
+                param.requires_grad = False
+
+    def encode_with_intermediate(self, input):
+        results = [input]
+        for i in range(self.n_layer):
+            results.append(getattr(self, "enc_{:d}".format(i + 1))(results[-1]))
+        return results[1:]
+
+    def encode(self, input):
+        for i in range(self.n_layer):
+            input = getattr(self, "enc_{:d}".format(i + 1))(input)
+        return input
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("Net.forward is the training-loss graph (net.py:199-226): out of scope for the "
+                                  "MI355X inference path; use field_retrieval()")
+
+    def field_retrieval(self, content, style_feats, alpha=1.0, unknown_distance=False):
+        assert 0 <= alpha <= 1
+        content_feat = self.encode(content)                      # logical NCHW, channels-last memory
+        feat_nhwc = ops.to_nhwc(content_feat)                    # free view
+        b = content.shape[0]
+        style_feats = style_feats.to(device=content_feat.device, dtype=torch.float32)
+        c = feat_nhwc.shape[-1]
+        if style_feats.shape[0] > 2:   # multiple style method: first half means, second half stds
+            half = style_feats.shape[0] // 2
+            style_mean, style_std = style_feats[:half].reshape(half, c), style_feats[half:].reshape(-1, c)
+            if half != b:
+                raise RuntimeError(f"multiple-style vector holds {half} styles for a batch of {b}")
+        else:                          # single style broadcast over the batch
+            style_mean, style_std = style_feats[:1].reshape(1, c), style_feats[1:].reshape(1, c)
+        mean, std = ops.channel_mean_std(feat_nhwc)
+        t = ops.adain_apply(feat_nhwc, mean, std, style_mean, style_std, float(alpha))
+        g_t = self.decoder.run_nhwc(t)                           # (B,2,S,S) planes
+        g_t_phase = g_t[:, 1:]
+        g_t = g_t[:, :1]
+        if unknown_distance:
+            # B == 1: the reference repeats the row to dodge InstanceNorm1d's batch-1 check and keeps row 0
+            # (net.py:255-256); the per-row normalisation here gives that same value directly.
+            return g_t, g_t_phase, self.distance_g((mean.view(b, c, 1, 1), std.view(b, c, 1, 1)))
+        return g_t, g_t_phase
+
+
+class Distance_G(nn.Module):
+    """net.py:266-327: MLP 1024 -> 1024 -> 1024 -> 512 -> 1 on [mean, std] statistics."""
+
+    def __init__(self):
+        super().__init__()
+        in_fc = 512 * 2
+        widths = [(in_fc, in_fc), (in_fc, in_fc), (in_fc, in_fc // 2)]
+        for k, (fin, fout) in enumerate(widths, start=1):
+            setattr(self, f"l{k}", nn.Linear(in_features=fin, out_features=fout, bias=True))
+            setattr(self, f"b{k}", nn.InstanceNorm1d(num_features=fout))
+            setattr(self, f"d{k}", nn.Dropout(p=0.5))
+        self.relu = nn.ReLU()
+        self.out = nn.Linear(in_features=in_fc // 2, out_features=1)
+        self.initialize_weights()
+
+    def forward(self, m_s):
+        m, s = m_s
+        assert m.shape == s.shape
+        if self.training:
+            raise NotImplementedError("Distance_G runs in eval mode only on this path (Dropout is the identity)")
+        b, c = m.shape[:2]
+        sd = {f"{n}.{p}": getattr(getattr(self, n), p) for n in ("l1", "l2", "l3", "out") for p in ("weight", "bias")}
+        return ops.distance_head(m.reshape(b, c).float(), s.reshape(b, c).float(), sd)
+
+    def initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)

@@ -1,0 +1,110 @@
+// Per-channel feature statistics and the stored-style AdaIN (function.py:4-23, net.py:235-246), NHWC.
+// Both are HBM-bound: one read of the (B,HW,C) map for the statistics, one read + one write for the apply.
+#include "common.h"
+
+namespace holo {
+
+// grid (C/64, B); 16 lanes x float4 cover 64 channels of one pixel (256 contiguous bytes),
+// 16 pixel groups per block stride over HW; sums are kept in float64 (the CPU reference's var/mean
+// accumulate in double as well), reduced through LDS.
+__global__ __launch_bounds__(256) void channel_mean_std_kernel(const float* __restrict__ x, float* __restrict__ mean,
+                                                               float* __restrict__ stdv, int hw, int c, float eps) {
+    __shared__ double s_sum[16][64];
+    __shared__ double s_sq[16][64];
+    const int tid = threadIdx.x;
+    const int cq = tid & 15, pg = tid >> 4;
+    const int c0 = blockIdx.x * 64;
+    const int b = blockIdx.y;
+    const float* __restrict__ xb = x + (size_t)b * hw * c + c0 + 4 * cq;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int p = pg; p < hw; p += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * c);
+        s[0] += v.x; q[0] += (double)v.x * v.x;
+        s[1] += v.y; q[1] += (double)v.y * v.y;
+        s[2] += v.z; q[2] += (double)v.z * v.z;
+        s[3] += v.w; q[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_sum[pg][4 * cq + j] = s[j];
+        s_sq[pg][4 * cq + j] = q[j];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double ts = 0, tq = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            ts += s_sum[g][tid];
+            tq += s_sq[g][tid];
+        }
+        const double n = (double)hw;
+        const double mu = ts / n;
+        double var = (tq - ts * mu) / (n - 1.0);  // unbiased (function.py:9: .var(dim=2))
+        var = var > 0 ? var : 0;
+        mean[(size_t)b * c + c0 + tid] = (float)mu;
+        stdv[(size_t)b * c + c0 + tid] = sqrtf((float)var + eps);  // function.py:9-10: var + eps, then sqrt, in fp32
+    }
+}
+
+__global__ __launch_bounds__(256) void adain_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv,
+                                                          const float* __restrict__ smean,
+                                                          const float* __restrict__ sstd, long sstride, float alpha,
+                                                          float one_minus_alpha, float* __restrict__ y, long total4,
+                                                          int hw, int c) {
+#pragma clang fp contract(off)
+    const int c4n = c >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        const long b = i / ((long)c4n * hw);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = reinterpret_cast<const float4*>(mean + b * c)[c4];
+        const float4 sd = reinterpret_cast<const float4*>(stdv + b * c)[c4];
+        const float4 sm = reinterpret_cast<const float4*>(smean + b * sstride)[c4];
+        const float4 ss = reinterpret_cast<const float4*>(sstd + b * sstride)[c4];
+        float4 o;
+        // net.py:241-246, same operation order: ((x-mu)/sd)*ss + sm, then alpha*t + (1-alpha)*x
+        o.x = alpha * (((v.x - mu.x) / sd.x) * ss.x + sm.x) + one_minus_alpha * v.x;
+        o.y = alpha * (((v.y - mu.y) / sd.y) * ss.y + sm.y) + one_minus_alpha * v.y;
+        o.z = alpha * (((v.z - mu.z) / sd.z) * ss.z + sm.z) + one_minus_alpha * v.z;
+        o.w = alpha * (((v.w - mu.w) / sd.w) * ss.w + sm.w) + one_minus_alpha * v.w;
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+}  // namespace holo
+
+extern "C" {
+
+int holo_channel_mean_std_f32(const float* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps,
+                              void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(x_nhwc && mean && std, HOLO_ERR_ARG, "holo_channel_mean_std_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && batch <= 65535 && hw >= 1 && c > 0 && c % 64 == 0, HOLO_ERR_ARG,
+                 "holo_channel_mean_std_f32: batch=%d hw=%d c=%d (c must be a multiple of 64, batch <= 65535)", batch,
+                 hw, c);
+    hipLaunchKernelGGL(channel_mean_std_kernel, dim3(c / 64, batch), dim3(256), 0, as_stream(stream), x_nhwc, mean, std,
+                       hw, c, eps);
+    return check_launch("holo_channel_mean_std_f32");
+}
+
+int holo_adain_apply_f32(const float* x_nhwc, const float* mean, const float* std, const float* style_mean,
+                         const float* style_std, long style_batch_stride, float alpha, float* y_nhwc, int batch, int hw,
+                         int c, void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(x_nhwc && mean && std && style_mean && style_std && y_nhwc, HOLO_ERR_ARG,
+                 "holo_adain_apply_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && hw >= 1 && c > 0 && c % 4 == 0 && style_batch_stride % 4 == 0, HOLO_ERR_ARG,
+                 "holo_adain_apply_f32: batch=%d hw=%d c=%d style_stride=%ld", batch, hw, c, style_batch_stride);
+    HOLO_REQUIRE(alpha >= 0.0f && alpha <= 1.0f, HOLO_ERR_ARG, "holo_adain_apply_f32: alpha=%f outside [0,1]", alpha);
+    const long total4 = (long)batch * hw * (c / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    // net.py:246: `(1 - alpha)` is evaluated in Python double precision, then meets the fp32 tensor
+    const float one_minus = (float)(1.0 - (double)alpha);
+    hipLaunchKernelGGL(adain_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x_nhwc, mean, std,
+                       style_mean, style_std, style_batch_stride, alpha, one_minus, y_nhwc, total4, hw, c);
+    return check_launch("holo_adain_apply_f32");
+}
+
+}  // extern "C"

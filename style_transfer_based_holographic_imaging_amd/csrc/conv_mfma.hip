@@ -1,0 +1,371 @@
+// fp32 implicit-GEMM convolutions on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, per layer, the aten chain  ReflectionPad2d(1) -> Conv2d(3x3) -> ReLU [-> MaxPool2d(2,2,
+// ceil_mode=True)]  of net.py:78-107 / net.py:34-71, and  ConvTranspose2d(k=2,s=2) -> ReLU  of
+// net.py:40,55,64.  The f32-input MFMA is an exact fp32 fmaf chain (no TF32 on gfx950), so results
+// differ from the CPU reference only by summation order.
+//
+// GEMM view:  out[pixel][co] = sum_{tap,ci} in[pixel + off(tap)][ci] * W[tap][ci][co]
+//   M = output pixels of one image patch (PR rows x 16 columns), N = output channels, K = 9*Cin.
+//   A block of 4 waves owns an (PR x 16) patch x TN channels; a wave owns 64 pixels x 64 channels
+//   as 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs).
+//
+// Data movement
+//   * activations are NHWC: a halo pixel's 16-channel chunk is 64 contiguous bytes (4 x 16-B units)
+//   * per 16-channel K chunk the (PR+2) x 18 halo is staged ONCE in LDS (reflection resolved by the
+//     loader) and reused by all 9 taps; weights are staged per (tap, chunk) as [co][16]
+//   * LDS rows are 64 B per pixel / per output channel; the 16-B unit index is XOR-swizzled with
+//     bits 2..3 of the row so that the ds_read_b128 of 32 rows spreads over the banks
+//   * a lane's ds_read_b128 returns 4 consecutive channels: lanes 0-31 read unit 2j, lanes 32-63 unit
+//     2j+1, which is exactly the k = lane>>5 split of the 32x32x2 MFMA (A and B use the same split,
+//     so no data permutation is needed — only the order of the k-sum changes)
+//   * register-prefetched double buffering: global loads of stage s+1 are issued before the 32 MFMAs
+//     of stage s and written to the other LDS buffer after them; one barrier per stage
+//
+// MFMA tile -> patch mapping (chosen so a 2x2 pooling window lies in 4 consecutive accumulator regs):
+//   tile row m (0..31):  x = (m&1) | ((m>>2)<<1),  y = (m>>1)&1          (2 rows x 16 columns)
+//   C/D layout: m = (reg&3) + 8*(reg>>2) + 4*(lane>>5), n = lane&31
+#include "common.h"
+
+namespace holo {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKC = 16;  // channels per K chunk
+constexpr int kPW = 16;  // patch width in pixels
+
+template <int WM, int WN, bool CONVT>
+struct ConvCfg {
+    static constexpr int PR = WM * 4;  // patch rows
+    static constexpr int TN = WN * 64;
+    static constexpr int HALO = CONVT ? 0 : 1;
+    static constexpr int HR = PR + 2 * HALO;
+    static constexpr int HW = kPW + 2 * HALO;
+    static constexpr int TAPS = CONVT ? 1 : 9;
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int A_UNITS = HR * HW * 4;  // 16-byte units per chunk
+    static constexpr int A_ROUNDS = (A_UNITS + THREADS - 1) / THREADS;
+    static constexpr int B_UNITS = TN * 4;
+    static constexpr int B_ROUNDS = (B_UNITS + THREADS - 1) / THREADS;
+    static constexpr int A_BYTES = HR * HW * 64;
+    static constexpr int B_BYTES = TN * 64;
+    static constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;
+    // A is re-staged every chunk; for CONVT every stage is a new chunk
+};
+
+__device__ __forceinline__ int swz(int row, int unit) { return row * 64 + ((unit ^ ((row >> 2) & 3)) << 4); }
+
+template <int WM, int WN, bool CONVT>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, int H, int W, int Cin, int Cout, int N, int tiles_x, int tiles_y, int relu, int pool) {
+    using C = ConvCfg<WM, WN, CONVT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_a = smem;                   // [2][A_BYTES]
+    unsigned char* lds_b = smem + 2 * C::A_BYTES;  // [2][B_BYTES]
+
+    const int tid = threadIdx.x;
+    const int n_blk = N / C::TN;
+    int bid = blockIdx.x;
+    const int nb = bid % n_blk;
+    bid /= n_blk;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int y0 = ty * C::PR, x0 = tx * kPW;
+    const int n0 = nb * C::TN;
+    const float* __restrict__ ximg = x + (size_t)img * H * W * Cin;
+    const int nchunks = Cin / kKC;
+    const int nstages = nchunks * C::TAPS;
+
+    // ---- staging plans (fixed per block) -------------------------------------------------------
+    int a_src[C::A_ROUNDS], a_dst[C::A_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < C::A_ROUNDS; ++r) {
+        const int u = tid + r * C::THREADS;
+        const int q = u >> 2, c = u & 3;
+        const int hy = q / C::HW, hx = q % C::HW;
+        const int ry = reflect1(y0 - C::HALO + hy, H);
+        const int rx = reflect1(x0 - C::HALO + hx, W);
+        a_src[r] = (ry * W + rx) * Cin + 4 * c;
+        a_dst[r] = (u < C::A_UNITS) ? swz(q, c) : -1;
+    }
+    int b_src[C::B_ROUNDS], b_dst[C::B_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < C::B_ROUNDS; ++r) {
+        const int u = tid + r * C::THREADS;
+        const int co = u >> 2, c = u & 3;
+        b_src[r] = co * kKC + 4 * c;
+        b_dst[r] = (u < C::B_UNITS) ? swz(co, c) : -1;
+    }
+    float4 a_reg[C::A_ROUNDS], b_reg[C::B_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < C::A_ROUNDS; ++r) a_reg[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < C::B_ROUNDS; ++r) b_reg[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+// Staging steps as macros (not lambdas: by-reference captures of the register arrays demote them to scratch).
+// packed weights: conv [tap][chunk][Cout][16], convT [chunk][4*Cout][16]; stage = chunk*TAPS + tap
+#define HOLO_LOAD_A(chunk_)                                                                              \
+    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                            \
+        if (a_dst[r] >= 0) a_reg[r] = *reinterpret_cast<const float4*>(ximg + a_src[r] + (chunk_) * kKC); \
+    }
+#define HOLO_STORE_A(buf_)                                                                               \
+    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                            \
+        if (a_dst[r] >= 0) *reinterpret_cast<float4*>(lds_a + (buf_) * C::A_BYTES + a_dst[r]) = a_reg[r]; \
+    }
+#define HOLO_LOAD_B(stage_)                                                                              \
+    {                                                                                                    \
+        const int chunk_b = (stage_) / C::TAPS, tap_b = (stage_) % C::TAPS;                              \
+        const float* __restrict__ wsrc = wp + ((size_t)(tap_b * nchunks + chunk_b) * N + n0) * kKC;      \
+        _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                        \
+            if (b_dst[r] >= 0) b_reg[r] = *reinterpret_cast<const float4*>(wsrc + b_src[r]);             \
+        }                                                                                                \
+    }
+#define HOLO_STORE_B(buf_)                                                                               \
+    _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                            \
+        if (b_dst[r] >= 0) *reinterpret_cast<float4*>(lds_b + (buf_) * C::B_BYTES + b_dst[r]) = b_reg[r]; \
+    }
+
+    // ---- per-lane MFMA operand coordinates -----------------------------------------------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hsel = lane >> 5, li = lane & 31;
+    const int lpx = (li & 1) | ((li >> 2) << 1);
+    const int lpy = wm * 4 + ((li >> 1) & 1);  // + 2*mt
+    int b_off[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) b_off[nt] = swz(wn * 64 + nt * 32 + li, hsel);
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    // ---- prologue ----------------------------------------------------------------------------------------
+    HOLO_LOAD_A(0)
+    HOLO_LOAD_B(0)
+    HOLO_STORE_A(0)
+    HOLO_STORE_B(0)
+    __syncthreads();
+
+    for (int s = 0; s < nstages; ++s) {
+        const int chunk = s / C::TAPS, tap = s % C::TAPS;
+        const bool has_next = (s + 1) < nstages;
+        const bool next_new_chunk = has_next && ((s + 1) % C::TAPS == 0);
+        if (has_next) HOLO_LOAD_B(s + 1)
+        if (next_new_chunk) { HOLO_LOAD_A(chunk + 1) }
+
+        const unsigned char* abuf = lds_a + (chunk & 1) * C::A_BYTES;
+        const unsigned char* bbuf = lds_b + (s & 1) * C::B_BYTES;
+        const int dy = CONVT ? 0 : tap / 3, dx = CONVT ? 0 : tap % 3;
+        int a_off[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int q = (lpy + 2 * mt + dy) * C::HW + lpx + dx;
+            a_off[mt] = swz(q, hsel);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 av[2], bv[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const float4*>(abuf + (a_off[mt] ^ (j << 5)));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bbuf + (b_off[nt] ^ (j << 5)));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float a = k == 0 ? av[mt].x : (k == 1 ? av[mt].y : (k == 2 ? av[mt].z : av[mt].w));
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const float b = k == 0 ? bv[nt].x : (k == 1 ? bv[nt].y : (k == 2 ? bv[nt].z : bv[nt].w));
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (has_next) { HOLO_STORE_B((s + 1) & 1) }
+        if (next_new_chunk) { HOLO_STORE_A((chunk + 1) & 1) }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, ReLU, optional 2x2 max-pool, NHWC store ------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 64 + nt * 32 + li;  // GEMM column
+        const int co = CONVT ? (n % Cout) : n;
+        const float bv = bias[co];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[mt][nt][r] + bv;
+                v[r] = relu ? fmaxf(t, 0.0f) : t;
+            }
+            if (CONVT) {
+                // n = q*Cout + co with q = dy*2+dx: output pixel (2Y+dy, 2X+dx)
+                const int qd = n / Cout;
+                const int ody = qd >> 1, odx = qd & 1;
+                float* __restrict__ yimg = y + (size_t)img * (2 * H) * (2 * W) * Cout;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                    const int X = x0 + ((m & 1) | ((m >> 2) << 1));
+                    const int Y = y0 + wm * 4 + mt * 2 + ((m >> 1) & 1);
+                    if (X < W && Y < H) yimg[((size_t)(2 * Y + ody) * (2 * W) + (2 * X + odx)) * Cout + co] = v[r];
+                }
+            } else if (!pool) {
+                float* __restrict__ yimg = y + (size_t)img * H * W * Cout;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                    const int X = x0 + ((m & 1) | ((m >> 2) << 1));
+                    const int Y = y0 + wm * 4 + mt * 2 + ((m >> 1) & 1);
+                    if (X < W && Y < H) yimg[((size_t)Y * W + X) * Cout + co] = v[r];
+                }
+            } else {
+                // MaxPool2d(2,2,ceil_mode=True): window = regs 4g..4g+3 (x bit0 = reg bit0, y bit0 = reg bit1);
+                // window members beyond the image edge are left out (post-ReLU values are >= 0)
+                const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+                float* __restrict__ yimg = y + (size_t)img * Ho * Wo * Cout;
+                const int Y = y0 + wm * 4 + mt * 2;  // even
+                const int PY = Y >> 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int X = x0 + ((hsel | (g << 1)) << 1);  // even
+                    const int PX = X >> 1;
+                    float mx = v[4 * g];
+                    if (X + 1 < W) mx = fmaxf(mx, v[4 * g + 1]);
+                    if (Y + 1 < H) {
+                        mx = fmaxf(mx, v[4 * g + 2]);
+                        if (X + 1 < W) mx = fmaxf(mx, v[4 * g + 3]);
+                    }
+                    if (X < W && Y < H) yimg[((size_t)PY * Wo + PX) * Cout + co] = mx;
+                }
+            }
+        }
+    }
+}
+
+#undef HOLO_LOAD_A
+#undef HOLO_STORE_A
+#undef HOLO_LOAD_B
+#undef HOLO_STORE_B
+
+template <int WM, int WN, bool CONVT>
+static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int batch, int h, int w, int cin,
+                       int cout, int relu, int pool, hipStream_t stream) {
+    using C = ConvCfg<WM, WN, CONVT>;
+    const int n = CONVT ? 4 * cout : cout;
+    const int tiles_x = ceil_div(w, kPW), tiles_y = ceil_div(h, C::PR);
+    const long blocks = (long)batch * tiles_x * tiles_y * (n / C::TN);
+    HOLO_REQUIRE(blocks > 0 && blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "conv: grid of %ld blocks", blocks);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (C::LDS_BYTES > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<WM, WN, CONVT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, CONVT>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
+                       stream, x, wp, bias, y, h, w, cin, cout, n, tiles_x, tiles_y, relu, pool);
+    return check_launch(CONVT ? "holo_convt2x2_f32" : "holo_conv3x3_f32");
+}
+
+// ---- weight packing --------------------------------------------------------------------------------------------
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin) {
+    const long total = (long)9 * cin * cout;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % kKC);
+    long r = i / kKC;
+    const int co = (int)(r % cout);
+    r /= cout;
+    const int nch = cin / kKC;
+    const int chunk = (int)(r % nch);
+    const int tap = (int)(r / nch);
+    const int ci = chunk * kKC + k;
+    out[i] = w[((long)co * cin + ci) * 9 + tap];  // OIHW, tap = ky*3+kx
+}
+
+__global__ void pack_convt2x2_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout) {
+    const long total = (long)4 * cin * cout;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % kKC);
+    long r = i / kKC;
+    const int n = (int)(r % (4 * cout));
+    const int chunk = (int)(r / (4 * cout));
+    const int q = n / cout, co = n % cout;
+    const int ci = chunk * kKC + k;
+    out[i] = w[((long)ci * cout + co) * 4 + q];  // (Cin,Cout,2,2), q = dy*2+dx
+}
+
+}  // namespace holo
+
+extern "C" {
+
+size_t holo_conv3x3_packed_elems(int cout, int cin) { return (size_t)9 * (size_t)cin * (size_t)cout; }
+size_t holo_convt2x2_packed_elems(int cin, int cout) { return (size_t)4 * (size_t)cin * (size_t)cout; }
+
+int holo_pack_conv3x3_weight_f32(const float* w_oihw, float* w_packed, int cout, int cin, void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(w_oihw && w_packed, HOLO_ERR_ARG, "holo_pack_conv3x3_weight_f32: null pointer");
+    HOLO_REQUIRE(cin > 0 && cout > 0 && cin % kKC == 0, HOLO_ERR_ARG,
+                 "holo_pack_conv3x3_weight_f32: Cin=%d must be a positive multiple of 16 (Cout=%d)", cin, cout);
+    const long total = (long)9 * cin * cout;
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       w_oihw, w_packed, cout, cin);
+    return check_launch("holo_pack_conv3x3_weight_f32");
+}
+
+int holo_pack_convt2x2_weight_f32(const float* w_iohw, float* w_packed, int cin, int cout, void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(w_iohw && w_packed, HOLO_ERR_ARG, "holo_pack_convt2x2_weight_f32: null pointer");
+    HOLO_REQUIRE(cin > 0 && cout > 0 && cin % kKC == 0, HOLO_ERR_ARG,
+                 "holo_pack_convt2x2_weight_f32: Cin=%d must be a positive multiple of 16 (Cout=%d)", cin, cout);
+    const long total = (long)4 * cin * cout;
+    hipLaunchKernelGGL(pack_convt2x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       w_iohw, w_packed, cin, cout);
+    return check_launch("holo_pack_convt2x2_weight_f32");
+}
+
+int holo_conv3x3_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc, int batch, int h,
+                     int w, int cin, int cout, int relu, int pool, void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc, HOLO_ERR_ARG, "holo_conv3x3_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG,
+                 "holo_conv3x3_f32: batch=%d h=%d w=%d (reflection padding needs h,w >= 2)", batch, h, w);
+    HOLO_REQUIRE(cin > 0 && cin % kKC == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_f32: Cin=%d must be a multiple of 16 and Cout=%d of 64", cin, cout);
+    HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_f32: fused pooling requires relu");
+    HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_f32: one image must stay below 2^31 elements");
+    hipStream_t s = as_stream(stream);
+    if (cout % 128 == 0) return launch_conv<2, 2, false>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+    return launch_conv<4, 1, false>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+}
+
+int holo_convt2x2_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc, int batch, int h,
+                      int w, int cin, int cout, int relu, void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc, HOLO_ERR_ARG, "holo_convt2x2_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 1 && w >= 1, HOLO_ERR_ARG, "holo_convt2x2_f32: batch=%d h=%d w=%d", batch, h, w);
+    HOLO_REQUIRE(cin > 0 && cin % kKC == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_convt2x2_f32: Cin=%d must be a multiple of 16 and Cout=%d of 64", cin, cout);
+    HOLO_REQUIRE((long)h * w * 4 * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
+                 "holo_convt2x2_f32: one image must stay below 2^31 elements");
+    // N = 4*Cout is always a multiple of 128 here (Cout % 64 == 0 -> a 128-wide tile may straddle two
+    // (dy,dx) quadrants only if Cout % 128 != 0; then use the 64-wide tile)
+    hipStream_t s = as_stream(stream);
+    if (cout % 128 == 0) return launch_conv<2, 2, true>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
+    return launch_conv<4, 1, true>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
+}
+
+}  // extern "C"

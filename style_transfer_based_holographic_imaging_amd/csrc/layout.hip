@@ -1,0 +1,46 @@
+// NCHW <-> NHWC transposes for callers that hand over / expect the reference's plane-major tensors
+// (e.g. a (B,512,h,w) feature map passed straight to the decoder).  32x32 LDS tiles, both sides coalesced.
+#include "common.h"
+
+namespace holo {
+
+// in: rows x cols (row-major) per batch item -> out: cols x rows
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                        int cols) {
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + i][tx] = in[base + (size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (r < rows && c < cols) out[base + (size_t)c * rows + r] = tile[tx][ty + i];
+    }
+}
+
+static int launch_transpose(const float* x, float* y, int batch, int rows, int cols, hipStream_t s, const char* what) {
+    HOLO_REQUIRE(x && y, HOLO_ERR_ARG, "%s: null pointer", what);
+    HOLO_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && cols > 0, HOLO_ERR_ARG, "%s: batch=%d rows=%d cols=%d", what,
+                 batch, rows, cols);
+    HOLO_REQUIRE(ceil_div(rows, 32) <= 65535, HOLO_ERR_UNSUPPORTED, "%s: %d rows too many", what, rows);
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32), batch), dim3(256), 0, s, x, y, rows,
+                       cols);
+    return check_launch(what);
+}
+
+}  // namespace holo
+
+extern "C" {
+int holo_nhwc_to_nchw_f32(const float* x, float* y, int batch, int hw, int c, void* stream) {
+    return holo::launch_transpose(x, y, batch, hw, c, holo::as_stream(stream), "holo_nhwc_to_nchw_f32");
+}
+int holo_nchw_to_nhwc_f32(const float* x, float* y, int batch, int hw, int c, void* stream) {
+    return holo::launch_transpose(x, y, batch, c, hw, holo::as_stream(stream), "holo_nchw_to_nhwc_f32");
+}
+}

@@ -1,0 +1,167 @@
+"""Layer plans: turn the reference's ``nn.Sequential`` layer lists into fused HIP launches.
+
+``net.vgg`` / ``net.decoder`` keep the reference's child layout (``net.py:33-130``) so that
+``load_state_dict``, ``list(vgg.children())[:31]`` and the slicing in ``Net.__init__`` work
+unchanged; the children are only parameter holders.  ``compile_plan`` pattern-matches a child list
+into steps, each one C-ABI call:
+
+    Conv2d(1,3,1x1) . ReflectionPad2d . Conv2d(3,64,3x3) . ReLU           -> conv_first
+    ReflectionPad2d . Conv2d(3x3) [. ReLU] [. MaxPool2d(2,2,ceil)]        -> conv3x3 (+relu, +pool)
+    ConvTranspose2d(k2,s2) [. ReLU]                                       -> convt2x2
+    ReflectionPad2d . Conv2d(64,2,3x3)                                    -> conv_last (NCHW planes out)
+
+Packed weights are cached per plan and rebuilt when a parameter changes (version counter / device).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Step:
+    __slots__ = ("kind", "conv", "conv0", "relu", "pool")
+
+    def __init__(self, kind, conv, conv0=None, relu=False, pool=False):
+        self.kind, self.conv, self.conv0, self.relu, self.pool = kind, conv, conv0, relu, pool
+
+    def __repr__(self):
+        c = self.conv
+        return f"Step({self.kind}, {tuple(c.weight.shape)}, relu={self.relu}, pool={self.pool})"
+
+
+def _is_reflpad1(m):
+    return isinstance(m, nn.ReflectionPad2d) and tuple(m.padding) == (1, 1, 1, 1)
+
+
+def _is_pool(m):
+    def two(v):
+        return v == 2 or tuple(v) == (2, 2)
+    return (isinstance(m, nn.MaxPool2d) and two(m.kernel_size) and two(m.stride) and m.ceil_mode
+            and (m.padding == 0 or tuple(m.padding) == (0, 0)))
+
+
+def compile_plan(children):
+    """children: list of nn.Module in reference order -> list[Step]; raises on anything unsupported."""
+    steps, i, n = [], 0, len(children)
+    while i < n:
+        m = children[i]
+        if isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1):
+            # vgg[0]: only the 1->3 pre-conv feeding the first 3x3 exists on this path
+            ok = (m.in_channels == 1 and m.out_channels == 3 and i + 2 < n and _is_reflpad1(children[i + 1])
+                  and isinstance(children[i + 2], nn.Conv2d) and children[i + 2].kernel_size == (3, 3)
+                  and children[i + 2].in_channels == 3 and children[i + 2].out_channels == 64
+                  and i + 3 < n and isinstance(children[i + 3], nn.ReLU))
+            if not ok:
+                raise NotImplementedError(f"unsupported 1x1 convolution at child {i}: {m}")
+            steps.append(Step("first", children[i + 2], conv0=m, relu=True))
+            i += 4
+        elif _is_reflpad1(m):
+            if not (i + 1 < n and isinstance(children[i + 1], nn.Conv2d) and children[i + 1].kernel_size == (3, 3)
+                    and children[i + 1].stride == (1, 1) and children[i + 1].padding == (0, 0)):
+                raise NotImplementedError(f"ReflectionPad2d at child {i} is not followed by a 3x3 Conv2d")
+            conv = children[i + 1]
+            i += 2
+            relu = i < n and isinstance(children[i], nn.ReLU)
+            i += int(relu)
+            pool = relu and i < n and _is_pool(children[i])
+            i += int(pool)
+            if conv.out_channels == 2 and conv.in_channels == 64 and not relu:
+                steps.append(Step("last", conv))
+            else:
+                if conv.in_channels % 16 or conv.out_channels % 64:
+                    raise NotImplementedError(
+                        f"3x3 conv {conv.in_channels}->{conv.out_channels}: the MFMA kernel needs Cin%16==0, Cout%64==0")
+                steps.append(Step("conv", conv, relu=relu, pool=pool))
+        elif isinstance(m, nn.ConvTranspose2d):
+            if not (m.kernel_size == (2, 2) and m.stride == (2, 2) and m.padding == (0, 0)
+                    and m.in_channels % 16 == 0 and m.out_channels % 64 == 0):
+                raise NotImplementedError(f"unsupported ConvTranspose2d at child {i}: {m}")
+            i += 1
+            relu = i < n and isinstance(children[i], nn.ReLU)
+            i += int(relu)
+            steps.append(Step("convt", m, relu=relu))
+        elif _is_pool(m):
+            raise NotImplementedError(f"MaxPool2d at child {i} does not follow a conv+ReLU (it is fused into one)")
+        else:
+            raise NotImplementedError(f"unsupported layer at child {i}: {m}")
+    return steps
+
+
+class Plan:
+    """Executable plan of one child list; owns the packed-weight cache."""
+
+    def __init__(self, children):
+        self.steps = compile_plan(list(children))
+        self._packed = {}
+
+    def _weights(self, idx, step):
+        conv = step.conv
+        key = (conv.weight._version, conv.weight.data_ptr(), conv.bias._version, conv.bias.data_ptr())
+        hit = self._packed.get(idx)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w = conv.weight.detach()
+        b = conv.bias.detach().float().contiguous()
+        if step.kind == "conv":
+            vals = (ops.pack_conv3x3(w), b)
+        elif step.kind == "convt":
+            vals = (ops.pack_convt2x2(w), b)
+        elif step.kind == "first":
+            c0 = step.conv0
+            vals = (c0.weight.detach().float().contiguous(), c0.bias.detach().float().contiguous(),
+                    w.float().contiguous(), b)
+        else:
+            vals = (w.float().contiguous(), b)
+        self._packed[idx] = (key, vals)
+        return vals
+
+    @property
+    def ends_in_planes(self):
+        return bool(self.steps) and self.steps[-1].kind == "last"
+
+    def run(self, x):
+        """x: logical (B,C,H,W) for a plan that starts with conv_first, else NHWC (B,H,W,C).
+        Returns NHWC, or NCHW (B,2,H,W) planes when the plan ends with conv_last."""
+        for idx, st in enumerate(self.steps):
+            wts = self._weights(idx, st)
+            if st.kind == "first":
+                if x.dim() != 4 or x.shape[1] != 1:
+                    raise RuntimeError(f"the encoder expects a (B,1,H,W) hologram amplitude, got {tuple(x.shape)}")
+                x = ops.conv_first(x, *wts)
+            elif st.kind == "conv":
+                x = ops.conv3x3(x, wts[0], wts[1], st.conv.out_channels, st.relu, st.pool)
+            elif st.kind == "convt":
+                x = ops.convt2x2(x, wts[0], wts[1], st.conv.out_channels, st.relu)
+            else:
+                x = ops.conv_last(x, wts[0], wts[1])
+        return x
+
+
+class HoloSequential(nn.Sequential):
+    """``nn.Sequential`` whose forward runs the fused HIP plan of its children.
+
+    Input: the reference's logical NCHW tensor on a ROCm device.  Output: logical NCHW — a
+    channels-last view of the NHWC result, or the contiguous (B,2,H,W) planes of the last decoder
+    layer.  CPU tensors raise: this path has no CPU fallback."""
+
+    def _plan(self):
+        sig = tuple(id(m) for m in self)
+        if getattr(self, "_holo_plan_sig", None) != sig:
+            object.__setattr__(self, "_holo_plan", Plan(list(self)))
+            object.__setattr__(self, "_holo_plan_sig", sig)
+        return self._holo_plan
+
+    def run_nhwc(self, x):
+        """NHWC in (or NCHW single-channel planes for a plan starting at vgg[0]) -> plan output."""
+        return self._plan().run(x)
+
+    def forward(self, input):
+        if not input.is_cuda:
+            raise RuntimeError("this network runs on MI355X HIP kernels only: move the input to a ROCm device "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure)")
+        plan = self._plan()
+        x = input if plan.steps and plan.steps[0].kind == "first" else ops.to_nhwc(input)
+        y = plan.run(x)
+        return y if plan.ends_in_planes else ops.as_nchw_view(y)

@@ -1,0 +1,353 @@
+"""Tensor-level wrappers over the C-ABI (``include/holo_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation below is a
+hand-written HIP kernel reached through ``_lib.lib``.  All functions require ROCm device tensors
+and raise otherwise — there is no CPU or aten fallback.
+
+Activations inside the network are NHWC: a ``(B,H,W,C)`` contiguous tensor.  ``as_nchw_view``
+exposes one as the reference's logical ``(B,C,H,W)`` shape without a copy (channels-last strides).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(*tensors):
+    for t in tensors:
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError(
+                "holo HIP ops need tensors on a ROCm device (the MI355X path has no CPU fallback); "
+                f"got {type(t).__name__} on {getattr(t, 'device', None)}")
+
+
+def _f32c(t):
+    """float32 + contiguous (no-op when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class KernelTimer:
+    """Per-launch timing with HIP events on the launch stream (torch's current stream is the stream
+    handed to the C-ABI).  Use as a context manager around the region to measure; ``summary()``
+    synchronises and returns {name: dict(calls, ms, flops, bytes)} with ALGORITHMIC flops/bytes."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _TIMER
+        self._prev, _TIMER = _TIMER, self
+        return self
+
+    def __exit__(self, *exc):
+        global _TIMER
+        _TIMER = self._prev
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            r = out.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            r["calls"] += 1
+            r["ms"] += e0.elapsed_time(e1)
+            r["flops"] += flops
+            r["bytes"] += nbytes
+        return out
+
+
+_TIMER = None
+
+
+def _launch(name, fn, flops=0.0, nbytes=0.0):
+    if _TIMER is None:
+        check(fn(), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(), name)
+    e1.record()
+    _TIMER.records.append((name, float(flops), float(nbytes), e0, e1))
+
+
+# ---------------------------------------------------------------------------------------------
+# layout
+# ---------------------------------------------------------------------------------------------
+def as_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Logical (B,C,H,W) tensor -> contiguous (B,H,W,C); free when already channels-last or C == 1."""
+    _req(x)
+    assert x.dim() == 4
+    b, c, h, w = x.shape
+    if x.dtype != torch.float32:
+        x = x.float()
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    if c == 1:
+        return x.contiguous().view(b, h, w, 1)
+    x = x.contiguous()
+    y = torch.empty((b, h, w, c), dtype=torch.float32, device=x.device)
+    _launch("holo_nchw_to_nhwc_f32", lambda: lib.holo_nchw_to_nhwc_f32(x.data_ptr(), y.data_ptr(), b, h * w, c, _stream()), nbytes=8.0 * b * h * w * c)
+    return y
+
+
+def to_nchw_contiguous(x_nhwc: torch.Tensor) -> torch.Tensor:
+    _req(x_nhwc)
+    b, h, w, c = x_nhwc.shape
+    x_nhwc = _f32c(x_nhwc)
+    y = torch.empty((b, c, h, w), dtype=torch.float32, device=x_nhwc.device)
+    _launch("holo_nhwc_to_nchw_f32", lambda: lib.holo_nhwc_to_nchw_f32(x_nhwc.data_ptr(), y.data_ptr(), b, h * w, c, _stream()), nbytes=8.0 * b * h * w * c)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------------------------
+def pack_conv3x3(w_oihw: torch.Tensor) -> torch.Tensor:
+    _req(w_oihw)
+    cout, cin, kh, kw = w_oihw.shape
+    assert (kh, kw) == (3, 3)
+    w = _f32c(w_oihw.detach())
+    out = torch.empty(lib.holo_conv3x3_packed_elems(cout, cin), dtype=torch.float32, device=w.device)
+    check(lib.holo_pack_conv3x3_weight_f32(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "holo_pack_conv3x3_weight_f32")
+    return out
+
+
+def pack_convt2x2(w_iohw: torch.Tensor) -> torch.Tensor:
+    _req(w_iohw)
+    cin, cout, kh, kw = w_iohw.shape
+    assert (kh, kw) == (2, 2)
+    w = _f32c(w_iohw.detach())
+    out = torch.empty(lib.holo_convt2x2_packed_elems(cin, cout), dtype=torch.float32, device=w.device)
+    check(lib.holo_pack_convt2x2_weight_f32(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "holo_pack_convt2x2_weight_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# convolutions
+# ---------------------------------------------------------------------------------------------
+def conv_first(x: torch.Tensor, w0, b0, w1, b1) -> torch.Tensor:
+    """vgg[0:4] (net.py:77-80): (B,1,H,W) -> NHWC (B,H,W,64)."""
+    _req(x, w0, b0, w1, b1)
+    b, c, h, w = x.shape
+    assert c == 1 and tuple(w0.shape) == (3, 1, 1, 1) and tuple(w1.shape) == (64, 3, 3, 3)
+    x = _f32c(x)
+    y = torch.empty((b, h, w, 64), dtype=torch.float32, device=x.device)
+    _launch("holo_conv_first_f32", lambda: lib.holo_conv_first_f32(x.data_ptr(), _f32c(w0.detach()).data_ptr(), _f32c(b0.detach()).data_ptr(),
+                                  _f32c(w1.detach()).data_ptr(), _f32c(b1.detach()).data_ptr(), y.data_ptr(),
+                                  b, h, w, _stream()), flops=2.0 * (27 * 64 + 3) * b * h * w, nbytes=4.0 * b * h * w * 65)
+    return y
+
+
+def conv3x3(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, relu=True, pool=False):
+    """ReflectionPad2d(1)+Conv2d(3x3)[+ReLU][+MaxPool2d(2,2,ceil_mode=True)] on NHWC."""
+    _req(x_nhwc, w_packed, bias)
+    b, h, w, cin = x_nhwc.shape
+    x_nhwc = _f32c(x_nhwc)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+    y = torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x_nhwc.device)
+    _launch("holo_conv3x3_f32", lambda: lib.holo_conv3x3_f32(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, cin,
+                               cout, int(relu), int(pool), _stream()), flops=2.0 * 9 * cin * cout * b * h * w, nbytes=4.0 * b * (h * w * cin + ho * wo * cout))
+    return y
+
+
+def convt2x2(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, relu=True):
+    """ConvTranspose2d(k=2,s=2)[+ReLU] on NHWC: (B,H,W,Cin) -> (B,2H,2W,Cout)."""
+    _req(x_nhwc, w_packed, bias)
+    b, h, w, cin = x_nhwc.shape
+    x_nhwc = _f32c(x_nhwc)
+    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x_nhwc.device)
+    _launch("holo_convt2x2_f32", lambda: lib.holo_convt2x2_f32(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, cin,
+                                cout, int(relu), _stream()), flops=2.0 * cin * 4 * cout * b * h * w, nbytes=4.0 * b * h * w * (cin + 4 * cout))
+    return y
+
+
+def conv_last(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """decoder[36:38] (net.py:72-73): NHWC (B,H,W,64) -> NCHW (B,2,H,W)."""
+    _req(x_nhwc, w_oihw, bias)
+    b, h, w, cin = x_nhwc.shape
+    assert cin == 64 and tuple(w_oihw.shape) == (2, 64, 3, 3)
+    x_nhwc = _f32c(x_nhwc)
+    y = torch.empty((b, 2, h, w), dtype=torch.float32, device=x_nhwc.device)
+    _launch("holo_conv_last_f32", lambda: lib.holo_conv_last_f32(x_nhwc.data_ptr(), _f32c(w_oihw.detach()).data_ptr(), _f32c(bias.detach()).data_ptr(),
+                                 y.data_ptr(), b, h, w, _stream()), flops=2.0 * 9 * 64 * 2 * b * h * w, nbytes=4.0 * b * h * w * 66)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# statistics / AdaIN
+# ---------------------------------------------------------------------------------------------
+def channel_mean_std(x_nhwc: torch.Tensor, eps: float = 1e-5):
+    """function.py:4-12 on NHWC: returns (mean, std) of shape (B,C)."""
+    _req(x_nhwc)
+    b, h, w, c = x_nhwc.shape
+    x_nhwc = _f32c(x_nhwc)
+    mean = torch.empty((b, c), dtype=torch.float32, device=x_nhwc.device)
+    std = torch.empty_like(mean)
+    _launch("holo_channel_mean_std_f32", lambda: lib.holo_channel_mean_std_f32(x_nhwc.data_ptr(), mean.data_ptr(), std.data_ptr(), b, h * w, c, float(eps),
+                                        _stream()), nbytes=4.0 * b * h * w * c)
+    return mean, std
+
+
+def adain_apply(x_nhwc, mean, std, style_mean, style_std, alpha: float = 1.0):
+    """net.py:241-246.  style_mean/style_std: (1,C) (broadcast) or (B,C)."""
+    _req(x_nhwc, mean, std, style_mean, style_std)
+    b, h, w, c = x_nhwc.shape
+    x_nhwc = _f32c(x_nhwc)
+    style_mean = _f32c(style_mean.reshape(-1, c))
+    style_std = _f32c(style_std.reshape(-1, c))
+    assert style_mean.shape == style_std.shape and style_mean.shape[0] in (1, b)
+    stride = 0 if style_mean.shape[0] == 1 and b != 1 else c
+    y = torch.empty_like(x_nhwc)
+    _launch("holo_adain_apply_f32", lambda: lib.holo_adain_apply_f32(x_nhwc.data_ptr(), mean.data_ptr(), std.data_ptr(), style_mean.data_ptr(),
+                                   style_std.data_ptr(), stride, float(alpha), y.data_ptr(), b, h * w, c, _stream()), nbytes=8.0 * b * h * w * c)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# distance head
+# ---------------------------------------------------------------------------------------------
+def linear(x, w, bias):
+    _req(x, w, bias)
+    x = _f32c(x)
+    bsz, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((bsz, n), dtype=torch.float32, device=x.device)
+    _launch("holo_linear_f32", lambda: lib.holo_linear_f32(x.data_ptr(), _f32c(w.detach()).data_ptr(), _f32c(bias.detach()).data_ptr(), y.data_ptr(),
+                              bsz, k, n, _stream()), flops=2.0 * bsz * k * n, nbytes=4.0 * (n * k + bsz * (k + n)))
+    return y
+
+
+def rownorm_relu(x, eps: float = 1e-5):
+    _req(x)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _launch("holo_rownorm_relu_f32", lambda: lib.holo_rownorm_relu_f32(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], float(eps), _stream()), nbytes=8.0 * x.numel())
+    return y
+
+
+def linear1_sigmoid(x, w, bias):
+    _req(x, w, bias)
+    x = _f32c(x)
+    y = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
+    _launch("holo_linear1_sigmoid_f32", lambda: lib.holo_linear1_sigmoid_f32(x.data_ptr(), _f32c(w.detach()).data_ptr(), _f32c(bias.detach()).data_ptr(),
+                                       y.data_ptr(), x.shape[0], x.shape[1], _stream()), nbytes=4.0 * x.numel())
+    return y
+
+
+def distance_head(mean, std, sd):
+    """net.py:288-308 on (B,C) statistics; ``sd`` maps l1/l2/l3/out .weight/.bias to device tensors."""
+    x = torch.cat([mean, std], dim=1)
+    for name in ("l1", "l2", "l3"):
+        x = rownorm_relu(linear(x, sd[f"{name}.weight"], sd[f"{name}.bias"]))
+    return linear1_sigmoid(x, sd["out.weight"], sd["out.bias"])
+
+
+# ---------------------------------------------------------------------------------------------
+# angular spectrum
+# ---------------------------------------------------------------------------------------------
+# fields per launch group: keeps the two S x P complex64 intermediates inside the 256 MiB Infinity Cache
+_ASM_CACHE_BUDGET = 160 << 20
+
+
+def phase_constant(d, n_fields: int, device) -> torch.Tensor:
+    """float64 constant c of theta = c*G per field, with the reference's rounding
+    (utils/Angular_Spectrum_Method.py:29): ``1j*2*pi*d`` is complex64 when d is a float32 tensor
+    — c = fl32(fl32(2 pi) * d) — and a float64 value when d is a Python float / float64 tensor."""
+    if isinstance(d, torch.Tensor):
+        if d.dtype == torch.float64:
+            c = (2 * math.pi) * d.to(device)
+        else:
+            c = (d.to(device=device, dtype=torch.float32) * (2 * math.pi)).double()  # fp32 multiply by fl32(2 pi)
+        c = c.reshape(-1)
+        if c.numel() == 1:
+            c = c.expand(n_fields)
+        assert c.numel() == n_fields, f"distance tensor has {c.numel()} entries for {n_fields} fields"
+        return c.contiguous()
+    return torch.full((n_fields,), 2 * math.pi * float(d), dtype=torch.float64, device=device)
+
+
+def _field_stride(t: torch.Tensor, s: int):
+    """Element stride between consecutive (b,c) fields of a (B,C,S,S) tensor whose planes are
+    contiguous, or None when the fields are not evenly spaced."""
+    b, c = t.shape[:2]
+    if t.stride(-1) != 1 or t.stride(-2) != s:
+        return None
+    if c == 1:
+        return t.stride(0) if b > 1 else s * s
+    if b == 1:
+        return t.stride(1)
+    return t.stride(1) if t.stride(0) == c * t.stride(1) else None
+
+
+def asm_propagate(in0, in1, phase_c, s, zero_padding, wavelength, pixel_size, phase_scale, out_mode, n_dist=1):
+    """Low-level launcher.  in0/in1: (B,C,S,S) float32 amplitude/phase (in1 not None) or in0 complex64.
+    phase_c: float64 (n_fields*n_dist,).  Returns (B*n_dist... ) shaped like (B,C*n_dist,S,S) outputs."""
+    _req(in0, phase_c)
+    b, ch = in0.shape[:2]
+    n_fields = b * ch
+    dev = in0.device
+    complex_in = in1 is None
+    if complex_in:
+        if in0.dtype != torch.complex64:
+            in0 = in0.to(torch.complex64)
+        st0 = _field_stride(in0, s)
+        if st0 is None:
+            in0 = in0.contiguous()
+            st0 = s * s
+        st1 = 0
+        p0, p1 = in0.data_ptr(), 0
+        in_mode = _lib.ASM_IN_COMPLEX
+    else:
+        _req(in1)
+        in0 = in0 if in0.dtype == torch.float32 else in0.float()
+        in1 = in1 if in1.dtype == torch.float32 else in1.float()
+        st0, st1 = _field_stride(in0, s), _field_stride(in1, s)
+        if st0 is None:
+            in0 = in0.contiguous()
+            st0 = s * s
+        if st1 is None:
+            in1 = in1.contiguous()
+            st1 = s * s
+        p0, p1 = in0.data_ptr(), in1.data_ptr()
+        in_mode = _lib.ASM_IN_AMP_PHASE
+    n_out = n_fields * n_dist
+    shape = (b, ch * n_dist, s, s)
+    if out_mode == _lib.ASM_OUT_COMPLEX:
+        out0 = torch.empty(shape, dtype=torch.complex64, device=dev)
+        out1 = None
+    else:
+        out0 = torch.empty(shape, dtype=torch.float32, device=dev)
+        out1 = torch.empty(shape, dtype=torch.float32, device=dev) if out_mode == _lib.ASM_OUT_AMP_PHASE else None
+    p = 2 * s if zero_padding else s
+    per_field = s * p * 8 * (1 + n_dist)
+    group = max(1, min(n_fields, _ASM_CACHE_BUDGET // per_field, 65535 // n_dist))
+    ws_bytes = lib.holo_asm_workspace_bytes(group, n_dist, s, int(bool(zero_padding)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    esz_in = 8 if complex_in else 4
+    esz_out = 8 if out_mode == _lib.ASM_OUT_COMPLEX else 4
+    plane = s * s
+    for f0 in range(0, n_fields, group):
+        nf = min(group, n_fields - f0)
+        _launch("holo_asm_propagate", lambda: lib.holo_asm_propagate(
+            p0 + f0 * st0 * esz_in, (p1 + f0 * st1 * 4) if p1 else 0, in_mode, st0, st1,
+            out0.data_ptr() + f0 * n_dist * plane * esz_out,
+            (out1.data_ptr() + f0 * n_dist * plane * 4) if out1 is not None else 0, out_mode, plane, plane,
+            phase_c.data_ptr() + f0 * n_dist * 8, nf, n_dist, s, int(bool(zero_padding)),
+            float(wavelength), float(pixel_size), float(phase_scale), ws.data_ptr(), ws_bytes, _stream()),
+                nbytes=(24.0 + 56.0 * n_dist) * plane * nf)
+    return out0, out1

@@ -1,0 +1,65 @@
+"""Drop-in for ``utils/Forward_model.py``: ``Holo_Generator`` on the fused HIP propagator.
+
+``Holo_Generator(args)`` reads ``wavelength, pixel_size, distance_normalize,
+distance_normalize_constant, phase_normalize`` from ``args`` (Forward_model.py:9-13);
+``forward(amplitude, phase, d, return_field=False, complex_number=False, unwrap=False)`` returns
+``(amp, phase)`` float32, the complex128 field, or the float32 intensity (Forward_model.py:16-39).
+The field packing ``amplitude*exp(1j*phase)`` and the abs/angle/|.|^2 epilogues are fused into the
+first and last propagation kernels, and strided views such as ``g_t[:, :1]`` are consumed in place.
+"""
+import torch
+from torch import nn
+
+from style_transfer_based_holographic_imaging_amd import _lib, ops
+from utils.functions import unwrap as uw
+
+
+class Holo_Generator(nn.Module):
+    def __init__(self, args):
+        super(Holo_Generator, self).__init__()
+        self.wavelength = args.wavelength
+        self.pixel_size = args.pixel_size
+        self.distance_normalize = args.distance_normalize
+        self.distance_normalize_constant = args.distance_normalize_constant
+        self.phase_normalize = args.phase_normalize
+
+    def _distance_m(self, d):
+        # Forward_model.py:18, float32 tensor arithmetic when d is a tensor
+        return ((d + self.distance_normalize_constant) * self.distance_normalize) * 1e-3
+
+    def forward(self, amplitude, phase, d, return_field=False, complex_number=False, unwrap=False):
+        b, c, s, s2 = amplitude.shape
+        if s != s2 or phase.shape != amplitude.shape:
+            raise RuntimeError(f"amplitude {tuple(amplitude.shape)} / phase {tuple(phase.shape)} must be equal and square")
+        d = self._distance_m(d)
+        if isinstance(d, torch.Tensor) and d.numel() > 1:
+            if d.numel() != b:
+                raise RuntimeError(f"distance tensor of {d.numel()} entries does not match batch {b}")
+            d = d.reshape(b, 1).expand(b, c).reshape(-1)
+        phase_c = ops.phase_constant(d, b * c, amplitude.device)
+        mode = (_lib.ASM_OUT_AMP_PHASE if return_field else
+                _lib.ASM_OUT_COMPLEX if complex_number else _lib.ASM_OUT_INTENSITY)
+        out0, out1 = ops.asm_propagate(amplitude, phase, phase_c, s, True, self.wavelength, self.pixel_size,
+                                       self.phase_normalize, mode)
+        if return_field:
+            return (out0, uw(out1)) if unwrap else (out0, out1)
+        if complex_number:
+            return out0.to(torch.complex128)
+        return out0
+
+    def sweep(self, amplitude, phase, distances, return_field=True):
+        """Propagate every field to all ``distances`` (1-D tensor / list, same units as ``d``): the
+        row-FFT pass runs once per field and only the column/inverse passes repeat.  Equivalent to the
+        reference idiom ``model_forward(a.repeat(n,1,1,1), p.repeat(n,1,1,1), distances)`` for one field
+        (utils/Data_loader.py:59-62).  Returns (B, n, S, S) tensors."""
+        b, c, s, _ = amplitude.shape
+        if c != 1:
+            raise RuntimeError("sweep expects single-channel fields")
+        dist = torch.as_tensor(distances, dtype=torch.float32, device=amplitude.device).reshape(-1)
+        n = dist.numel()
+        d = self._distance_m(dist).reshape(1, n).expand(b, n).reshape(-1)
+        phase_c = ops.phase_constant(d, b * n, amplitude.device)
+        mode = _lib.ASM_OUT_AMP_PHASE if return_field else _lib.ASM_OUT_INTENSITY
+        out0, out1 = ops.asm_propagate(amplitude, phase, phase_c, s, True, self.wavelength, self.pixel_size,
+                                       self.phase_normalize, mode, n_dist=n)
+        return (out0, out1) if return_field else out0

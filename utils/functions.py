@@ -1,0 +1,37 @@
+"""Drop-in for the hot-path helpers of ``utils/functions.py``: ``field_retrieval`` (functions.py:22-29)
+and ``unwrap`` (functions.py:44-59).  The plotting / loss helpers of the reference are not on the
+inference path."""
+import torch
+
+
+def field_retrieval(network, content, style_vector, alpha=1.0, unkonwn_distance=False):
+    assert (0.0 <= alpha <= 1.0)
+    if unkonwn_distance:
+        amplitude, phase, distance_content = network.field_retrieval(content, style_vector, alpha, unkonwn_distance)
+        return amplitude, phase, distance_content.view(-1, 1, 1, 1)
+    amplitude, phase = network.field_retrieval(content, style_vector, alpha)
+    return amplitude, phase
+
+
+def unwrap(x):
+    """Per-image 2-D phase unwrapping on the host with scikit-image, as the reference does.  The
+    dependency is third-party native code the reference neither vendors nor pins; where it is not
+    installed this raises instead of inventing a result (parity for unwrap is unpinned)."""
+    try:
+        from skimage.restoration import unwrap_phase
+    except ImportError as e:
+        raise ImportError("utils.functions.unwrap needs scikit-image (skimage.restoration.unwrap_phase), "
+                          "which is not installed; call Holo_Generator(..., unwrap=False)") from e
+    x = x.cpu().detach().numpy()
+    out = []
+    for i in range(x.shape[0]):
+        ph = x[i]
+        if ph.ndim > 2:
+            ph = ph.squeeze()
+        out.append(torch.from_numpy(unwrap_phase(ph)).unsqueeze(0).unsqueeze(0))
+    return torch.cat(out, dim=0)
+
+
+def center_crop(H, size):
+    batch, channel, Nh, Nw = H.size()
+    return H[:, :, (Nh - size) // 2:(Nh + size) // 2, (Nw - size) // 2:(Nw + size) // 2]

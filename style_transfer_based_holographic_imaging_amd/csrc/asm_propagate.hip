@@ -5,62 +5,116 @@
 //
 // out = crop( ifft2( H . fft2( replicate_pad(O) ) ) ),  H[ky][kx] = exp(i*c*sqrt(max(0,1-l^2 f^2))/l)
 //
-// fftshift/ifftshift (even P) only relabel the bins, so H is evaluated at the signed frequency of
-// the un-shifted bin and no shift pass exists.  The P x P complex grid does not fit a CU's LDS, so
-// the 2-D transform is three HBM-bound kernels (80*S^2 algorithmic bytes per field):
+// fftshift/ifftshift only relabel the bins, so H is evaluated at the signed frequency of the
+// un-shifted bin and no shift pass exists.  The P x P complex grid does not fit a CU's LDS, so the
+// 2-D transform is three HBM-bound kernels (80*S^2 algorithmic bytes per field):
 //
 //   K1 rows_fwd : amp,phase (8S^2 B) -> pack a*e^{ip}, replicate-pad the ROW to P, row FFT
 //                 -> T[S][P] (16S^2 B).  The S/2 padded rows above/below the field are copies of
-//                 its first/last row, so only S distinct row FFTs exist.
-//   K2 cols     : T columns (16S^2 B) -> replicate-pad the COLUMN to P in LDS, column FFT,
-//                 multiply by H generated on the fly (float64 phase argument, range-reduced, then
-//                 fp32 sincos), column IFFT, keep the S centre rows -> U[S][P] (16S^2 B)
+//                 its first/last row, so only S distinct row FFTs exist.  Inputs go straight from
+//                 global memory into the first butterfly's registers, outputs straight from the last
+//                 butterfly's registers to global memory (LDS only between passes).
+//   K2 cols     : T columns (16S^2 B) -> transposed into LDS, column FFT (replicate padding applied
+//                 by the first gather), multiply by H IN REGISTERS between the forward's last and the
+//                 inverse's first pass (same radix, same register layout), column IFFT, keep the S
+//                 centre rows -> U[S][P] (16S^2 B).  H is generated per block: float64 phase argument
+//                 from a precomputed f^2 table, range reduction in float64, fp32 sin/cos; rows ky and
+//                 P-ky share one value through an LDS table.
 //   K3 rows_inv : U rows (16S^2 B) -> row IFFT, keep the S centre columns, scale 1/P^2,
-//                 abs/angle | intensity | complex epilogue (8S^2 B)
+//                 abs/angle | intensity | complex epilogue (8S^2 B), again register to global.
 //
 // Transforms run in fp32 (complex64) with float64-rounded twiddles; the reference runs the product
 // and the inverse transform in complex128 and casts to float at the end
 // (Angular_Spectrum_Method.py:29-33, Forward_model.py:28-29) — measured difference ~2e-7 relative.
+#include <cstdlib>
 #include "common.h"
 #include "fft_lds.h"
 
 namespace holo {
 
-constexpr int kThreads = 256;
-constexpr int kRowPad = 16;  // complex elements of padding between sequences in the row kernels
-constexpr int kColPad = 17;  // column pitch P+17: transposed b64 stores of 16 columns hit 16 bank pairs
+constexpr int kRowThreads = 256;
 
-__global__ void asm_twiddle_kernel(float2* tw, int p) {
+// ---- tables: twiddles exp(-2 pi i m / P) and squared signed frequencies (k/(P px))^2 ------------------
+__global__ void asm_tables_kernel(float2* tw, double* f2, int p, double ppx) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m < p) {
         double s, c;
         sincospi(-2.0 * (double)m / (double)p, &s, &c);
         tw[m] = make_float2((float)c, (float)s);
+        // numpy: fx = (arange(2S)/2 - S//2)/(S*px)  ==  signed_bin/(P*px) bit for bit; then fx**2
+        const int ks = m < p / 2 ? m : m - p;
+        const double f = (double)ks / ppx;
+        f2[m] = f * f;
     }
+}
+
+// sin/cos for arguments of moderate size: Cody-Waite reduction by pi/2 with FMA (three-part constant),
+// minimax polynomials on [-pi/4, pi/4]; ~1 ulp.  Large arguments take the library path.
+__device__ __forceinline__ void sincos_poly(float r, int q, float* s, float* c) {
+    const float z = r * r;
+    const float sp = r + r * z * (-1.6666667163e-01f + z * (8.3333337680e-03f + z * (-1.9841270114e-04f + z * 2.7557314297e-06f)));
+    const float cp = 1.0f - 0.5f * z + z * z * (4.1666667908e-02f + z * (-1.3888889225e-03f + z * 2.4801587642e-05f));
+    const float ss = (q & 1) ? cp : sp;
+    const float cc = (q & 1) ? sp : cp;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+__device__ __forceinline__ void sincos_f32(float x, float* s, float* c) {
+    if (fabsf(x) > 8192.0f) {
+        sincosf(x, s, c);
+        return;
+    }
+    const float n = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-n, 1.5707963705062866f, x);
+    r = fmaf(-n, -4.371138828673793e-08f, r);
+    r = fmaf(-n, -1.7151245100058819e-15f, r);
+    sincos_poly(r, (int)n & 3, s, c);
 }
 
 __device__ __forceinline__ float2 load_field(const float* __restrict__ in0, const float* __restrict__ in1,
                                              int in_mode, long off0, long off1, float phase_scale) {
-    if (in_mode == HOLO_ASM_IN_COMPLEX) {
-        return reinterpret_cast<const float2*>(in0)[off0];
-    }
+    if (in_mode == HOLO_ASM_IN_COMPLEX) return reinterpret_cast<const float2*>(in0)[off0];
     // Forward_model.py:20-22: phase*phase_normalize, then amplitude*exp(1j*phase) in complex64
     const float a = in0[off0];
     const float p = in1[off1] * phase_scale;
     float s, c;
-    sincosf(p, &s, &c);
+    sincos_f32(p, &s, &c);
     return make_float2(a * c, a * s);
+}
+
+// H value for squared frequencies fx2 + fy2: theta = (c/l) * sqrt(max(0, 1 - l^2 (fx^2+fy^2)))
+// (Angular_Spectrum_Method.py:22-29).  float64 up to the reduced angle (theta reaches ~1e4 rad and must be
+// good to ~1e-6 rad), then fp32 sin/cos of the remainder.
+__device__ __forceinline__ float2 transfer_value(double sum_f2, double lam2, double c_over_l) {
+    const double g = 1.0 - lam2 * sum_f2;
+    double root = 0.0;
+    if (g > 0.0) {
+        const double y = __builtin_amdgcn_rsq(g);       // ~2^-26 relative
+        const double s0 = g * y;
+        root = __builtin_fma(__builtin_fma(-s0, s0, g), 0.5 * y, s0);  // one Newton step: ~2^-52
+    }
+    const double turns = (c_over_l * root) * 0.15915494309189533577;   // theta / 2 pi
+    const float fr = (float)(turns - rint(turns));                     // [-0.5, 0.5] revolutions
+    const float m = rintf(fr * 4.0f);
+    const float r = (fr - m * 0.25f) * 6.28318530717958647692f;        // [-pi/4, pi/4]
+    float s, c;
+    sincos_poly(r, (int)m & 3, &s, &c);
+    return make_float2(c, s);
 }
 
 // ---- K1: pack + pad + row FFT ------------------------------------------------------------------
 template <int P, bool PAD>
-__global__ __launch_bounds__(kThreads) void asm_rows_fwd_kernel(
+__global__ __launch_bounds__(kRowThreads) void asm_rows_fwd_kernel(
     const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
     float phase_scale, float2* __restrict__ tbuf, const float2* __restrict__ tw_g, long n_rows) {
     constexpr int S = PAD ? P / 2 : P;
-    constexpr int G = P / 8;            // threads per sequence
-    constexpr int SEQ = kThreads / G;   // sequences per block
-    constexpr int PITCH = P + kRowPad;
+    constexpr int G = P / 8;               // threads per row, 8 elements each
+    constexpr int SEQ = kRowThreads / G;   // rows per block
+    constexpr int E = 8;
+    constexpr int PITCH = fft_padded_len(P) + 1;
+    constexpr int R1 = fft_radix<P, -1>(0);
+    constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);
     float2* buf = tw + P;
@@ -70,62 +124,69 @@ __global__ __launch_bounds__(kThreads) void asm_rows_fwd_kernel(
     const long row = (long)blockIdx.x * SEQ + seq;
     const bool valid = row < n_rows;
     float2* my = buf + seq * PITCH;
-    for (int i = tid; i < P; i += kThreads) tw[i] = tw_g[i];
-    if (valid) {
-        const long f = row / S;
-        const int y = (int)(row % S);
-        for (int x = t; x < S; x += G) {
-            const long pix = (long)y * S + x;
-            my[x + (PAD ? S / 2 : 0)] =
-                load_field(in0, in1, in_mode, f * stride0 + pix, f * stride1 + pix, phase_scale);
+    for (int i = tid; i < P; i += kRowThreads) tw[i] = tw_g[i];
+
+    float2 v[E];
+    {
+        const long f = valid ? row / S : 0;
+        const int y = valid ? (int)(row % S) : 0;
+        const long base0 = f * stride0 + (long)y * S, base1 = f * stride1 + (long)y * S;
+        float2 edge0 = make_float2(0.f, 0.f), edge1 = edge0;
+        if (PAD) {  // F.pad(..., mode="replicate") along the row (Angular_Spectrum_Method.py:12)
+            edge0 = load_field(in0, in1, in_mode, base0, base1, phase_scale);
+            edge1 = load_field(in0, in1, in_mode, base0 + S - 1, base1 + S - 1, phase_scale);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r = e % R1;
+            // element index i = j + r*P/R1 with j < P/R1: the pad regions are whole r-slices
+            const bool left = PAD && (r + 1) * 4 <= R1;
+            const bool right = PAD && r * 4 >= 3 * R1;
+            if (left) {
+                v[e] = edge0;
+            } else if (right) {
+                v[e] = edge1;
+            } else {
+                const int i = fft_elem_index<P, G, R1>(t, e);
+                const int col = PAD ? i - S / 2 : i;
+                v[e] = load_field(in0, in1, in_mode, base0 + col, base1 + col, phase_scale);
+            }
         }
     }
-    __syncthreads();
-    if (PAD) {
-        // F.pad(..., mode="replicate") along the row (Angular_Spectrum_Method.py:12)
-        const float2 a = my[S / 2], b = my[S / 2 + S - 1];
-        for (int c = t; c < S / 2; c += G) {
-            my[c] = a;
-            my[3 * S / 2 + c] = b;
-        }
-        __syncthreads();
-    }
-    fft_inplace<P, 1, G, -1>(my, tw, t);
+    __syncthreads();  // twiddle table
+    fft_run<P, G, -1>(v, my, tw, t);
     if (valid) {
         float2* dst = tbuf + row * P;
-        for (int k = t; k < P; k += G) dst[k] = my[k];
+#pragma unroll
+        for (int e = 0; e < E; ++e) dst[fft_elem_index<P, G, RL>(t, e)] = v[e];
     }
 }
 
 // ---- K2: column FFT . H . column IFFT -----------------------------------------------------------
-// theta = c * sqrt(max(0, 1 - l^2 (fx^2+fy^2))) / l evaluated as numpy does
-// (Angular_Spectrum_Method.py:16-23), in float64 with no contraction.
-__device__ __forceinline__ float2 transfer_value(double fx2, double fy, double lam2, double lamb, double c) {
-#pragma clang fp contract(off)
-    const double sum = fx2 + fy * fy;
-    const double g = 1.0 - lam2 * sum;
-    const double gg = sqrt(g > 0.0 ? g : 0.0) / lamb;
-    const double theta = c * gg;
-    // reduce to [-pi, pi] in float64, then fp32 sincos
-    constexpr double INV_2PI = 0.15915494309189533577;
-    constexpr double TWO_PI_HI = 6.283185307179586232;     // double(2*pi)
-    constexpr double TWO_PI_LO = 2.4492935982947064e-16;   // 2*pi - double(2*pi)
-    const double n = rint(theta * INV_2PI);
-    double r = __builtin_fma(-n, TWO_PI_HI, theta);
-    r = __builtin_fma(-n, TWO_PI_LO, r);
-    float s, co;
-    sincosf((float)r, &s, &co);
-    return make_float2(co, s);
-}
+template <int P>
+struct ColCfg {
+    // columns per block: 16 x 8 B = one 128-B line per row; fewer only where LDS runs out
+    static constexpr int CW = P >= 2048 ? 4 : (P >= 1024 ? 8 : 16);
+    // threads per column: 16 elements per thread from P = 256 up (8 below), i.e. <= 128 VGPRs so that
+    // two 512-thread blocks (16 waves) share a CU; 32 elements/thread measured 1 block/CU and 4x slower
+    static constexpr int G = P >= 256 ? P / 16 : P / 8;
+    static constexpr int THREADS = CW * G;
+    static constexpr int E = P / G;
+    static constexpr int PITCH = fft_padded_len(P) + 16 / CW;   // transposed b64 stores spread over the banks
+    static constexpr size_t LDS = (size_t)(P + CW * PITCH) * sizeof(float2);
+};
 
-template <int P, bool PAD, int CW>
-__global__ __launch_bounds__(kThreads) void asm_cols_kernel(
+template <int P, bool PAD>
+__global__ __launch_bounds__(ColCfg<P>::THREADS, (ColCfg<P>::THREADS >= 256 ? 4 : 1)) void asm_cols_kernel(
     const float2* __restrict__ tbuf, float2* __restrict__ ubuf, const float2* __restrict__ tw_g,
-    const double* __restrict__ phase_const, int n_dist, double ppx, double lam2, double lamb) {
+    const double* __restrict__ f2_g, const double* __restrict__ phase_const, int n_dist, double lam2, double lamb,
+    int ablate) {
+    using C = ColCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
-    constexpr int OFF = PAD ? S / 2 : 0;
-    constexpr int G = kThreads / CW;  // threads per column
-    constexpr int PITCH = P + kColPad;
+    constexpr int CW = C::CW, G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
+    constexpr int R1 = fft_radix<P, -1>(0);
+    constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);  // forward's last = inverse's first radix
+    static_assert(fft_radix<P, +1>(0) == RL && fft_radix<P, +1>(FftPlan<P>::n - 1) == R1, "plan symmetry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);
     float2* cols = tw + P;
@@ -134,67 +195,71 @@ __global__ __launch_bounds__(kThreads) void asm_cols_kernel(
     const int fo = blockIdx.y;          // output field = field * n_dist + dist
     const int f = fo / n_dist;
     const int kx0 = blockIdx.x * CW;
-    for (int i = tid; i < P; i += kThreads) tw[i] = tw_g[i];
+    for (int i = tid; i < P; i += THREADS) tw[i] = tw_g[i];
+    // coalesced read of S rows x CW columns, transposed into per-column sequences (compact: S entries)
     const float2* src = tbuf + (long)f * S * P + kx0;
-    for (int i = tid; i < S * CW; i += kThreads) {
+    for (int i = tid; i < S * CW; i += THREADS) {
         const int y = i / CW, cl = i % CW;
-        cols[cl * PITCH + y + OFF] = src[(long)y * P + cl];
+        cols[cl * PITCH + fft_pad(y)] = src[(long)y * P + cl];
     }
     __syncthreads();
-    if (PAD) {
-        // replicate rows above/below the field: copies of its first/last row spectrum
-        for (int i = tid; i < (S / 2) * CW; i += kThreads) {
-            const int r = i / CW, cl = i % CW;
-            cols[cl * PITCH + r] = cols[cl * PITCH + S / 2];
-            cols[cl * PITCH + 3 * S / 2 + r] = cols[cl * PITCH + 3 * S / 2 - 1];
-        }
-        __syncthreads();
-    }
     const int col = tid / G, t = tid % G;
     float2* my = cols + col * PITCH;
-    fft_inplace<P, 1, G, -1>(my, tw, t);
+    float2 v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = fft_elem_index<P, G, R1>(t, e);
+        // replicate rows above/below the field are copies of its first/last row spectrum
+        int y = PAD ? i - S / 2 : i;
+        y = y < 0 ? 0 : (y > S - 1 ? S - 1 : y);
+        v[e] = my[fft_pad(y)];
+    }
+    if (!(ablate & 2)) fft_run<P, G, -1>(v, my, tw, t);   // spectrum now in registers at ky = fft_elem_index<P,G,RL>(t,e)
 
+    // transfer function: one value per (column, |ky|), shared through LDS by rows ky and P-ky
+    __syncthreads();                   // all gathers of the last forward pass are done: `cols` is free
     {
-        const double c = phase_const[fo];
-        const int kx = kx0 + col;
-        const int kxs = kx < P / 2 ? kx : kx - P;   // signed frequency index of the un-shifted bin
-        double fx2;
-        {
-#pragma clang fp contract(off)
-            const double fx = (double)kxs / ppx;
-            fx2 = fx * fx;
-        }
-        // rows ky and P-ky share fy^2: one transfer value serves both
-        for (int m = t; m <= P / 2; m += G) {
-            double fy;
-            {
-#pragma clang fp contract(off)
-                fy = (double)m / ppx;
-            }
-            const float2 h = transfer_value(fx2, fy, lam2, lamb, c);
-            my[m] = cmul(my[m], h);
-            if (m != 0 && m != P / 2) my[P - m] = cmul(my[P - m], h);
-        }
+        const double c_over_l = phase_const[fo] / lamb;
+        const double fx2 = f2_g[kx0 + col];
+        for (int m = t; m <= P / 2; m += G)
+            my[m] = (ablate & 1) ? make_float2(1.f, 0.f) : transfer_value(fx2 + f2_g[m], lam2, c_over_l);
     }
     __syncthreads();
-    fft_inplace<P, 1, G, +1>(my, tw, t);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int ky = fft_elem_index<P, G, RL>(t, e);
+        v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
+    }
+    if (!(ablate & 2)) fft_run<P, G, +1>(v, my, tw, t);   // first barrier inside protects the table reads above
 
+    // keep the S centre rows; transpose back through LDS for a coalesced store
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = fft_elem_index<P, G, R1>(t, e);
+        const int y = PAD ? i - S / 2 : i;
+        if (y >= 0 && y < S) my[fft_pad(y)] = v[e];
+    }
+    __syncthreads();
     float2* dst = ubuf + (long)fo * S * P + kx0;
-    for (int i = tid; i < S * CW; i += kThreads) {
+    for (int i = tid; i < S * CW; i += THREADS) {
         const int y = i / CW, cl = i % CW;
-        dst[(long)y * P + cl] = cols[cl * PITCH + y + OFF];
+        dst[(long)y * P + cl] = cols[cl * PITCH + fft_pad(y)];
     }
 }
 
 // ---- K3: row IFFT + crop + epilogue ---------------------------------------------------------------
 template <int P, bool PAD>
-__global__ __launch_bounds__(kThreads) void asm_rows_inv_kernel(
+__global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
     const float2* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode,
     long ostride0, long ostride1, const float2* __restrict__ tw_g, long n_rows, float scale) {
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = P / 8;
-    constexpr int SEQ = kThreads / G;
-    constexpr int PITCH = P + kRowPad;
+    constexpr int SEQ = kRowThreads / G;
+    constexpr int E = 8;
+    constexpr int PITCH = fft_padded_len(P) + 1;
+    constexpr int R1 = fft_radix<P, +1>(0);
+    constexpr int RL = fft_radix<P, +1>(FftPlan<P>::n - 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tw = reinterpret_cast<float2*>(smem_raw);
     float2* buf = tw + P;
@@ -204,30 +269,37 @@ __global__ __launch_bounds__(kThreads) void asm_rows_inv_kernel(
     const long row = (long)blockIdx.x * SEQ + seq;
     const bool valid = row < n_rows;
     float2* my = buf + seq * PITCH;
-    for (int i = tid; i < P; i += kThreads) tw[i] = tw_g[i];
-    if (valid) {
-        const float2* src = ubuf + row * P;
-        for (int k = t; k < P; k += G) my[k] = src[k];
+    for (int i = tid; i < P; i += kRowThreads) tw[i] = tw_g[i];
+    float2 v[E];
+    {
+        const float2* src = ubuf + (valid ? row : 0) * P;
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = src[fft_elem_index<P, G, R1>(t, e)];
     }
     __syncthreads();
-    fft_inplace<P, 1, G, +1>(my, tw, t);
+    fft_run<P, G, +1>(v, my, tw, t);
     if (valid) {
         const long fo = row / S;
         const int y = (int)(row % S);
-        for (int x = t; x < S; x += G) {
-            float2 v = my[x + (PAD ? S / 2 : 0)];
-            v.x *= scale;
-            v.y *= scale;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r = e % RL;
+            // centre crop (Angular_Spectrum_Method.py:34): with padding only the middle r-slices survive
+            if (PAD && ((r + 1) * 4 <= RL || r * 4 >= 3 * RL)) continue;
+            const int i = fft_elem_index<P, G, RL>(t, e);
+            const int x = PAD ? i - S / 2 : i;
+            float2 o = v[e];
+            o.x *= scale;
+            o.y *= scale;
             const long pix = (long)y * S + x;
             if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
-                out0[fo * ostride0 + pix] = sqrtf(v.x * v.x + v.y * v.y);
-                out1[fo * ostride1 + pix] = atan2f(v.y, v.x);
+                out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
+                out1[fo * ostride1 + pix] = atan2f(o.y, o.x);
             } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
-                // Forward_model.py:39: pow(abs(.),2)
-                const float a = sqrtf(v.x * v.x + v.y * v.y);
+                const float a = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
                 out0[fo * ostride0 + pix] = a * a;
             } else {
-                reinterpret_cast<float2*>(out0)[fo * ostride0 + pix] = v;
+                reinterpret_cast<float2*>(out0)[fo * ostride0 + pix] = o;
             }
         }
     }
@@ -245,21 +317,25 @@ struct AsmArgs {
     int n_fields, n_dist;
     double ppx, lam2, lamb;
     float phase_scale;
-    float2 *tw, *tbuf, *ubuf;
+    float2* tw;
+    double* f2;
+    float2 *tbuf, *ubuf;
     hipStream_t stream;
+    int ablate;   // debug only (HOLO_ASM_ABLATE): 1 = skip H evaluation, 2 = skip the FFT passes
 };
 
-template <int P, bool PAD, int CW>
+template <int P, bool PAD>
 static int launch_asm(const AsmArgs& a) {
+    using C = ColCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = P / 8;
-    constexpr int SEQ = kThreads / G;
-    const size_t row_lds = (size_t)(P + SEQ * (P + kRowPad)) * sizeof(float2);
-    const size_t col_lds = (size_t)(P + CW * (P + kColPad)) * sizeof(float2);
+    constexpr int SEQ = kRowThreads / G;
+    const size_t row_lds = (size_t)(P + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
+    const size_t col_lds = C::LDS;
     static bool attr_done = false;  // idempotent; a race only repeats the call
     if (!attr_done) {
         if (col_lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_kernel<P, PAD, CW>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
         if (row_lds > 48 * 1024) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_kernel<P, PAD>),
@@ -269,23 +345,25 @@ static int launch_asm(const AsmArgs& a) {
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(asm_twiddle_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, a.stream, a.tw, P);
+    hipLaunchKernelGGL(asm_tables_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, a.stream, a.tw, a.f2, P, a.ppx);
     const long rows_in = (long)a.n_fields * S;
-    hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kThreads),
+    hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kRowThreads),
                        row_lds, a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale, a.tbuf, a.tw, rows_in);
-    hipLaunchKernelGGL((asm_cols_kernel<P, PAD, CW>), dim3(P / CW, a.n_fields * a.n_dist), dim3(kThreads), col_lds,
-                       a.stream, a.tbuf, a.ubuf, a.tw, a.phase_const, a.n_dist, a.ppx, a.lam2, a.lamb);
+    hipLaunchKernelGGL((asm_cols_kernel<P, PAD>), dim3(P / C::CW, a.n_fields * a.n_dist), dim3(C::THREADS), col_lds,
+                       a.stream, a.tbuf, a.ubuf, a.tw, a.f2, a.phase_const, a.n_dist, a.lam2, a.lamb, a.ablate);
     const long rows_out = rows_in * a.n_dist;
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
-    hipLaunchKernelGGL((asm_rows_inv_kernel<P, PAD>), dim3((unsigned)((rows_out + SEQ - 1) / SEQ)), dim3(kThreads),
+    hipLaunchKernelGGL((asm_rows_inv_kernel<P, PAD>), dim3((unsigned)((rows_out + SEQ - 1) / SEQ)), dim3(kRowThreads),
                        row_lds, a.stream, a.ubuf, a.out0, a.out1, a.out_mode, a.os0, a.os1, a.tw, rows_out, scale);
     return check_launch("holo_asm_propagate");
 }
 
-template <int P, int CW>
+template <int P>
 static int launch_asm_pad(const AsmArgs& a, bool pad) {
-    return pad ? launch_asm<P, true, CW>(a) : launch_asm<P, false, CW>(a);
+    return pad ? launch_asm<P, true>(a) : launch_asm<P, false>(a);
 }
+
+constexpr size_t kTableBytes = 2048 * sizeof(float2) + 2048 * sizeof(double);
 
 }  // namespace holo
 
@@ -295,7 +373,7 @@ size_t holo_asm_workspace_bytes(int n_fields, int n_dist, int s, int zero_paddin
     if (n_fields <= 0 || n_dist <= 0 || s <= 0) return 0;
     const size_t p = zero_padding ? 2 * (size_t)s : (size_t)s;
     const size_t slab = (size_t)s * p * sizeof(float2);
-    return 2048 * sizeof(float2) + slab * (size_t)n_fields + slab * (size_t)n_fields * (size_t)n_dist;
+    return holo::kTableBytes + slab * (size_t)n_fields + slab * (size_t)n_fields * (size_t)n_dist;
 }
 
 int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_stride, long in1_stride,
@@ -336,25 +414,29 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
     a.phase_const = phase_const;
     a.n_fields = n_fields;
     a.n_dist = n_dist;
-    // numpy: fx = (arange(2S)/2 - S//2)/(S*px) == signed_bin/(P*px) bit for bit (scaling by 2 is exact)
-    a.ppx = (double)s * pixel_size * (zero_padding ? 2.0 : 1.0);
+    a.ppx = (double)s * pixel_size * (zero_padding ? 2.0 : 1.0);  // P*px; scaling by 2 is exact
     a.lam2 = wavelength * wavelength;
     a.lamb = wavelength;
     a.phase_scale = phase_scale;
     a.tw = static_cast<float2*>(workspace);
-    a.tbuf = a.tw + 2048;
+    a.f2 = reinterpret_cast<double*>(a.tw + 2048);
+    a.tbuf = reinterpret_cast<float2*>(static_cast<unsigned char*>(workspace) + kTableBytes);
     a.ubuf = a.tbuf + (size_t)n_fields * s * p;
     a.stream = as_stream(stream);
+    {
+        const char* env = getenv("HOLO_ASM_ABLATE");
+        a.ablate = env ? atoi(env) : 0;
+    }
     const bool pad = zero_padding != 0;
     switch (p) {
-        case 16: return launch_asm_pad<16, 16>(a, pad);
-        case 32: return launch_asm_pad<32, 16>(a, pad);
-        case 64: return launch_asm_pad<64, 16>(a, pad);
-        case 128: return launch_asm_pad<128, 16>(a, pad);
-        case 256: return launch_asm_pad<256, 16>(a, pad);
-        case 512: return launch_asm_pad<512, 16>(a, pad);
-        case 1024: return launch_asm_pad<1024, 8>(a, pad);
-        case 2048: return launch_asm_pad<2048, 4>(a, pad);
+        case 16: return launch_asm_pad<16>(a, pad);
+        case 32: return launch_asm_pad<32>(a, pad);
+        case 64: return launch_asm_pad<64>(a, pad);
+        case 128: return launch_asm_pad<128>(a, pad);
+        case 256: return launch_asm_pad<256>(a, pad);
+        case 512: return launch_asm_pad<512>(a, pad);
+        case 1024: return launch_asm_pad<1024>(a, pad);
+        case 2048: return launch_asm_pad<2048>(a, pad);
     }
     return HOLO_ERR_UNSUPPORTED;
 }

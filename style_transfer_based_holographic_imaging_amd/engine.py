@@ -121,21 +121,24 @@ class Plan:
     def ends_in_planes(self):
         return bool(self.steps) and self.steps[-1].kind == "last"
 
+    def run_step(self, idx, x):
+        st = self.steps[idx]
+        wts = self._weights(idx, st)
+        if st.kind == "first":
+            if x.dim() != 4 or x.shape[1] != 1:
+                raise RuntimeError(f"the encoder expects a (B,1,H,W) hologram amplitude, got {tuple(x.shape)}")
+            return ops.conv_first(x, *wts)
+        if st.kind == "conv":
+            return ops.conv3x3(x, wts[0], wts[1], st.conv.out_channels, st.relu, st.pool)
+        if st.kind == "convt":
+            return ops.convt2x2(x, wts[0], wts[1], st.conv.out_channels, st.relu)
+        return ops.conv_last(x, wts[0], wts[1])
+
     def run(self, x):
         """x: logical (B,C,H,W) for a plan that starts with conv_first, else NHWC (B,H,W,C).
         Returns NHWC, or NCHW (B,2,H,W) planes when the plan ends with conv_last."""
-        for idx, st in enumerate(self.steps):
-            wts = self._weights(idx, st)
-            if st.kind == "first":
-                if x.dim() != 4 or x.shape[1] != 1:
-                    raise RuntimeError(f"the encoder expects a (B,1,H,W) hologram amplitude, got {tuple(x.shape)}")
-                x = ops.conv_first(x, *wts)
-            elif st.kind == "conv":
-                x = ops.conv3x3(x, wts[0], wts[1], st.conv.out_channels, st.relu, st.pool)
-            elif st.kind == "convt":
-                x = ops.convt2x2(x, wts[0], wts[1], st.conv.out_channels, st.relu)
-            else:
-                x = ops.conv_last(x, wts[0], wts[1])
+        for idx in range(len(self.steps)):
+            x = self.run_step(idx, x)
         return x
 
 

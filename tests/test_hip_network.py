@@ -160,3 +160,20 @@ def test_256_against_oracle(env, mnist_style):
     for got, ref32, truth in ((amp, o[0], a64), (p, o[1], p64)):
         assert rel_err(got.cpu(), truth) < 4.0 * rel_err(ref32, truth) + 1e-6
     assert cplx_rel(fld, f64) < 4.0 * cplx_rel(o[5], f64) + 1e-6
+
+
+def test_entry_script_runs_the_bundled_data(tmp_path, monkeypatch, capsys):
+    """The drop-in entry point over the 20 bundled files (config 1 plumbing), synthetic weights."""
+    import test_field_retrieval_mnist as entry
+    monkeypatch.chdir(REPO)
+    rc = entry.main(["--device", "cuda", "--synthetic-weights", "0", "--save_dir", str(tmp_path), "--unwrap", "off"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Mean PSNR" in out and "Mean MAE" in out and "R2 score" in out
+    pngs = sorted(os.listdir(tmp_path / "MNIST_test"))
+    assert len([p for p in pngs if p.endswith("_test.png")]) == 100
+    with open(tmp_path / "MNIST_test" / "1_test.png", "rb") as f:
+        head = f.read(24)
+    assert head[:8] == b"\x89PNG\r\n\x1a\n"
+    import struct
+    w, h = struct.unpack(">II", head[16:24])
+    assert (w, h) == (512, 256)            # 4 x 128 wide, 2 x 128 tall mosaics like the reference's

@@ -1,0 +1,158 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/holo_hip.h
+declares, argument validation rejects bad calls before any launch, the plan compiler fuses the
+reference's layer lists as documented, state-dict key compatibility, and loud failures on CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "holo_hip.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(holo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from style_transfer_based_holographic_imaging_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/holo_hip.h but not exported"
+    assert set(declared) == set(_lib.SIGNATURES), "ctypes SIGNATURES and the header disagree"
+    assert _lib.lib.holo_abi_version() == 1
+    assert _lib.lib.holo_target_arch() == b"gfx950"
+
+
+def test_argument_validation_needs_no_gpu():
+    """Every entry point validates before launching: these return error codes on a GPU-less host."""
+    from style_transfer_based_holographic_imaging_amd._lib import lib
+    assert lib.holo_conv3x3_f32(None, None, None, None, 1, 4, 4, 16, 64, 1, 0, None) == 1
+    assert b"null pointer" in lib.holo_last_error()
+    fake = ctypes.c_void_p(16)
+    assert lib.holo_conv3x3_f32(fake, fake, fake, fake, 1, 1, 4, 16, 64, 1, 0, None) == 1       # H < 2
+    assert b"reflection padding" in lib.holo_last_error()
+    assert lib.holo_conv3x3_f32(fake, fake, fake, fake, 1, 4, 4, 24, 64, 1, 0, None) == 2       # Cin % 16
+    assert lib.holo_conv3x3_f32(fake, fake, fake, fake, 1, 4, 4, 16, 64, 0, 1, None) == 2       # pool without relu
+    assert lib.holo_asm_propagate(fake, fake, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 40, 1, 5e-7, 1e-6, 1.0,
+                                  fake, 1 << 30, None) == 2                                      # P = 80
+    assert b"power of two" in lib.holo_last_error()
+    assert lib.holo_asm_propagate(fake, fake, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 64, 1, 5e-7, 1e-6, 1.0,
+                                  fake, 16, None) == 3                                           # workspace
+    assert lib.holo_asm_propagate(fake, None, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 64, 1, 5e-7, 1e-6, 1.0,
+                                  fake, 1 << 30, None) == 1                                      # missing phase
+    assert lib.holo_adain_apply_f32(fake, fake, fake, fake, fake, 0, 1.5, fake, 1, 4, 64, None) == 1  # alpha
+    assert lib.holo_asm_workspace_bytes(2, 3, 64, 1) == 2048 * 8 + 2048 * 8 + 64 * 128 * 8 * (2 + 6)
+    assert lib.holo_conv3x3_packed_elems(128, 64) == 9 * 64 * 128
+
+
+def test_state_dict_surface_matches_reference_keys():
+    import net
+    from style_transfer_based_holographic_imaging_amd import synth
+    vgg_sd, dec_sd, dist_sd = synth.synthetic_state_dicts(1, full_vgg=True)
+    assert len(list(net.vgg.children())) == 53 and len(list(net.decoder.children())) == 38
+    assert set(net.vgg.state_dict()) == set(vgg_sd) and len(vgg_sd) == 34
+    assert set(net.decoder.state_dict()) == set(dec_sd) and len(dec_sd) == 28
+    assert set(net.Distance_G().state_dict()) == set(dist_sd) == {f"{n}.{p}" for n in ("l1", "l2", "l3", "out")
+                                                                    for p in ("weight", "bias")}
+    for k, v in net.decoder.state_dict().items():
+        assert v.shape == dec_sd[k].shape, k
+    # weight surgery of the entry script (test_field_retrieval_mnist.py:87) keeps working
+    assert net.vgg.state_dict()["0.weight"].shape == (3, 1, 1, 1)
+    # ConvTranspose2d weights are (Cin, Cout, 2, 2)
+    assert net.decoder.state_dict()["6.weight"].shape == (256, 256, 2, 2)
+
+
+def test_plan_compiler_fuses_reference_layer_lists():
+    import net
+    from style_transfer_based_holographic_imaging_amd.engine import compile_plan
+    enc = nn.Sequential(*list(net.vgg.children())[:31])
+    network = net.Net(enc, net.decoder, None, net.Distance_G())
+    assert network.n_layer == 4
+    kinds = [[(s.kind, s.conv.out_channels, s.relu, s.pool) for s in getattr(network, f"enc_{k}")._plan().steps]
+             for k in range(1, 5)]
+    assert kinds[0] == [("first", 64, True, False)]
+    assert kinds[1] == [("conv", 64, True, True), ("conv", 128, True, False)]
+    assert kinds[2] == [("conv", 128, True, True), ("conv", 256, True, False)]
+    assert kinds[3] == [("conv", 256, True, False)] * 2 + [("conv", 256, True, True), ("conv", 512, True, False)]
+    dec = [(s.kind, s.conv.out_channels) for s in network.decoder._plan().steps]
+    assert dec == [("conv", 512), ("conv", 256), ("convt", 256), ("conv", 256), ("conv", 256), ("conv", 256),
+                   ("conv", 128), ("convt", 128), ("conv", 128), ("conv", 64), ("convt", 64), ("conv", 64),
+                   ("conv", 64), ("last", 2)]
+    # the full 53-layer encoder gives a fifth stage (net.py:152-153)
+    full = net.Net(net.vgg, net.decoder)
+    assert full.n_layer == 5 and len(full.enc_5._plan().steps) == 4
+    for p in network.enc_1.parameters():
+        assert p.requires_grad is False          # net.py:167-170
+    with pytest.raises(NotImplementedError):
+        compile_plan([nn.Conv2d(3, 8, 5)])
+    with pytest.raises(NotImplementedError):
+        compile_plan([nn.ReflectionPad2d(1), nn.Conv2d(24, 64, 3), nn.ReLU()])
+
+
+def test_cpu_tensors_fail_loudly():
+    import function
+    import net
+    from utils.Angular_Spectrum_Method import ASM
+    from utils.Forward_model import Holo_Generator
+    from utils.functions import field_retrieval
+    import types
+    enc = nn.Sequential(*list(net.vgg.children())[:31])
+    network = net.Net(enc, net.decoder, None, net.Distance_G()).eval()
+    x = torch.rand(1, 1, 16, 16)
+    sv = torch.rand(2, 512, 1, 1)
+    with pytest.raises(RuntimeError, match="ROCm device|HIP kernels only"):
+        field_retrieval(network, x, sv, 1.0, True)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        function.calc_mean_std(torch.rand(1, 64, 4, 4))
+    with pytest.raises(AssertionError):
+        function.calc_mean_std(torch.rand(64, 4, 4))
+    hp = types.SimpleNamespace(wavelength=532e-9, pixel_size=1.5e-6, distance_normalize=1.0,
+                               distance_normalize_constant=0.0, phase_normalize=1.0)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        Holo_Generator(hp)(torch.ones(1, 1, 16, 16), torch.zeros(1, 1, 16, 16), 0.3)
+    with pytest.raises(RuntimeError, match="square"):
+        ASM(torch.zeros(1, 1, 8, 16, dtype=torch.complex64), 5e-7, 1e-4, 1e-6)
+    with pytest.raises(AssertionError):
+        field_retrieval(network, x, sv, 1.2)
+    with pytest.raises(NotImplementedError):
+        network(x, x)                              # Net.forward = training graph: out of scope
+
+
+def test_phase_constant_rounding_chain():
+    """c = fl32(fl32(2 pi) * d) for a float32 distance tensor, float64 2*pi*d for a Python float
+    (utils/Angular_Spectrum_Method.py:29)."""
+    import math
+    import numpy as np
+    from style_transfer_based_holographic_imaging_amd import ops
+    d = torch.tensor([4e-4, -2e-4, 8e-4], dtype=torch.float32)
+    c = ops.phase_constant(d, 3, torch.device("cpu"))
+    expect = (np.float32(2 * math.pi) * d.numpy().astype(np.float32)).astype(np.float64)
+    assert c.dtype == torch.float64 and np.array_equal(c.numpy(), expect)
+    ref = (1j * 2 * math.pi * d).imag.double()        # the reference's own expression
+    assert torch.equal(c, ref)
+    c2 = ops.phase_constant(3.0e-4, 2, torch.device("cpu"))
+    assert c2.tolist() == [2 * math.pi * 3.0e-4] * 2
+    with pytest.raises(AssertionError):
+        ops.phase_constant(d, 4, torch.device("cpu"))
+
+
+def test_synthetic_generators_are_deterministic():
+    from style_transfer_based_holographic_imaging_amd import synth
+    a = synth.synthetic_state_dicts(3)
+    b = synth.synthetic_state_dicts(3)
+    assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and len(a[0]) == 20
+    full = synth.synthetic_state_dicts(3, full_vgg=True)[0]
+    assert all(torch.equal(full[k], a[0][k]) for k in a[0])
+    p = synth.synthetic_phase_objects(2, 64, seed=5)
+    assert p.shape == (2, 1, 64, 64) and float(p.min()) == 0.0 and float(p.max()) <= 1.0
+    assert torch.equal(p, synth.synthetic_phase_objects(2, 64, seed=5))
+    assert (p[:, :, :16] == 0).all() and (p[:, :, :, -16:] == 0).all()   # zero border

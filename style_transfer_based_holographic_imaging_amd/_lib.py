@@ -13,7 +13,8 @@ import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64.so.7 / l
 #                      would bind the process to /opt/rocm's runtime and split streams and memory across two runtimes
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libholo_hip.so")
+# HOLO_HIP_LIB selects another build of the same ABI (A/B experiments); default = the in-tree library
+LIB_PATH = os.environ.get("HOLO_HIP_LIB") or os.path.join(_HERE, "libholo_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int

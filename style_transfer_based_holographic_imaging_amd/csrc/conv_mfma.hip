@@ -27,6 +27,10 @@
 //   C/D layout: m = (reg&3) + 8*(reg>>2) + 4*(lane>>5), n = lane&31
 #include "common.h"
 
+#ifndef HOLO_CONV_GLDS
+#define HOLO_CONV_GLDS 1   // 1: LDS-DMA staging (global_load_lds_dwordx4); 0: register staging
+#endif
+
 namespace holo {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -80,53 +84,94 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
     const int nstages = nchunks * C::TAPS;
 
     // ---- staging plans (fixed per block) -------------------------------------------------------
-    int a_src[C::A_ROUNDS], a_dst[C::A_ROUNDS];
+    // 16-byte unit u = tid + r*THREADS of the LDS image holds unit (u&3) ^ swizzle of halo pixel / output
+    // channel u>>2.  With LDS-DMA the destination is lane-linear (wave base + lane*16), so the XOR swizzle
+    // is applied to the per-lane SOURCE address; the ds_read side applies the same XOR (swz()).
+    int a_src[C::A_ROUNDS];
 #pragma unroll
     for (int r = 0; r < C::A_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
-        const int q = u >> 2, c = u & 3;
+        const int q = u >> 2, c = (u & 3) ^ ((q >> 2) & 3);
         const int hy = q / C::HW, hx = q % C::HW;
         const int ry = reflect1(y0 - C::HALO + hy, H);
         const int rx = reflect1(x0 - C::HALO + hx, W);
         a_src[r] = (ry * W + rx) * Cin + 4 * c;
-        a_dst[r] = (u < C::A_UNITS) ? swz(q, c) : -1;
     }
-    int b_src[C::B_ROUNDS], b_dst[C::B_ROUNDS];
+    int b_src[C::B_ROUNDS];
 #pragma unroll
     for (int r = 0; r < C::B_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
-        const int co = u >> 2, c = u & 3;
+        const int co = u >> 2, c = (u & 3) ^ ((co >> 2) & 3);
         b_src[r] = co * kKC + 4 * c;
-        b_dst[r] = (u < C::B_UNITS) ? swz(co, c) : -1;
     }
+#if HOLO_CONV_GLDS
+    // global_load_lds_dwordx4: no staging VGPRs, no ds_write; completion = s_waitcnt vmcnt(0) before the barrier
+    const int wave_base = (tid & ~63) * 16;   // byte offset of this wave's first unit within a round
+    const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
+// Issued from inline asm on purpose: through the builtin, hipcc orders every later ds_read behind the
+// pending LDS write and drains vmcnt(0) before the first fragment read of the stage (seen in the ISA),
+// which serialises the DMA with the MFMAs.  The asm form is invisible to that pass; completion is our
+// own s_waitcnt vmcnt(0) right before the stage barrier.  M0 (LDS base of the DMA) is saved/restored.
+#define HOLO_GLDS16(gsrc_, ldst_)                                                                          \
+    {                                                                                                     \
+        unsigned m0_keep;                                                                                 \
+        const unsigned lds_u = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(ldst_));              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t" \
+                     "s_mov_b32 m0, %0"                                                                    \
+                     : "=&s"(m0_keep)                                                                     \
+                     : "v"(gsrc_), "s"(lds_u)                                                             \
+                     : "memory");                                                                         \
+    }
+#define HOLO_LOAD_A(chunk_, buf_)                                                                         \
+    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
+        if (tid + r * C::THREADS < C::A_UNITS)                                                            \
+            HOLO_GLDS16(ximg + a_src[r] + (chunk_) * kKC,                                                 \
+                        (buf_) * C::A_BYTES + r * C::THREADS * 16 + wave_base)                           \
+    }
+#define HOLO_LOAD_B(stage_, buf_)                                                                         \
+    {                                                                                                     \
+        const int chunk_b = (stage_) / C::TAPS, tap_b = (stage_) % C::TAPS;                               \
+        const float* __restrict__ wsrc = wp + ((size_t)(tap_b * nchunks + chunk_b) * N + n0) * kKC;       \
+        _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                         \
+            if (tid + r * C::THREADS < C::B_UNITS)                                                        \
+                HOLO_GLDS16(wsrc + b_src[r], 2 * C::A_BYTES + (buf_) * C::B_BYTES + r * C::THREADS * 16 + wave_base) \
+        }                                                                                                 \
+    }
+#define HOLO_STORE_A(buf_)
+#define HOLO_STORE_B(buf_)
+#define HOLO_STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+    // register staging: global loads issued before the MFMAs of a stage, ds_write after them
     float4 a_reg[C::A_ROUNDS], b_reg[C::B_ROUNDS];
 #pragma unroll
     for (int r = 0; r < C::A_ROUNDS; ++r) a_reg[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < C::B_ROUNDS; ++r) b_reg[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-// Staging steps as macros (not lambdas: by-reference captures of the register arrays demote them to scratch).
-// packed weights: conv [tap][chunk][Cout][16], convT [chunk][4*Cout][16]; stage = chunk*TAPS + tap
-#define HOLO_LOAD_A(chunk_)                                                                              \
-    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                            \
-        if (a_dst[r] >= 0) a_reg[r] = *reinterpret_cast<const float4*>(ximg + a_src[r] + (chunk_) * kKC); \
+#define HOLO_LOAD_A(chunk_, buf_)                                                                         \
+    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
+        if (tid + r * C::THREADS < C::A_UNITS)                                                            \
+            a_reg[r] = *reinterpret_cast<const float4*>(ximg + a_src[r] + (chunk_) * kKC);                \
     }
-#define HOLO_STORE_A(buf_)                                                                               \
-    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                            \
-        if (a_dst[r] >= 0) *reinterpret_cast<float4*>(lds_a + (buf_) * C::A_BYTES + a_dst[r]) = a_reg[r]; \
+#define HOLO_STORE_A(buf_)                                                                                \
+    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
+        if (tid + r * C::THREADS < C::A_UNITS)                                                            \
+            *reinterpret_cast<float4*>(lds_a + (buf_) * C::A_BYTES + (tid + r * C::THREADS) * 16) = a_reg[r]; \
     }
-#define HOLO_LOAD_B(stage_)                                                                              \
-    {                                                                                                    \
-        const int chunk_b = (stage_) / C::TAPS, tap_b = (stage_) % C::TAPS;                              \
-        const float* __restrict__ wsrc = wp + ((size_t)(tap_b * nchunks + chunk_b) * N + n0) * kKC;      \
-        _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                        \
-            if (b_dst[r] >= 0) b_reg[r] = *reinterpret_cast<const float4*>(wsrc + b_src[r]);             \
-        }                                                                                                \
+#define HOLO_LOAD_B(stage_, buf_)                                                                         \
+    {                                                                                                     \
+        const int chunk_b = (stage_) / C::TAPS, tap_b = (stage_) % C::TAPS;                               \
+        const float* __restrict__ wsrc = wp + ((size_t)(tap_b * nchunks + chunk_b) * N + n0) * kKC;       \
+        _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                         \
+            if (tid + r * C::THREADS < C::B_UNITS) b_reg[r] = *reinterpret_cast<const float4*>(wsrc + b_src[r]); \
+        }                                                                                                 \
     }
-#define HOLO_STORE_B(buf_)                                                                               \
-    _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                            \
-        if (b_dst[r] >= 0) *reinterpret_cast<float4*>(lds_b + (buf_) * C::B_BYTES + b_dst[r]) = b_reg[r]; \
+#define HOLO_STORE_B(buf_)                                                                                \
+    _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                             \
+        if (tid + r * C::THREADS < C::B_UNITS)                                                            \
+            *reinterpret_cast<float4*>(lds_b + (buf_) * C::B_BYTES + (tid + r * C::THREADS) * 16) = b_reg[r]; \
     }
+#define HOLO_STAGE_WAIT()
+#endif
 
     // ---- per-lane MFMA operand coordinates -----------------------------------------------------------
     const int lane = tid & 63, wave = tid >> 6;
@@ -155,18 +200,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
             }
 
     // ---- prologue ----------------------------------------------------------------------------------------
-    HOLO_LOAD_A(0)
-    HOLO_LOAD_B(0)
+    HOLO_LOAD_A(0, 0)
+    HOLO_LOAD_B(0, 0)
     HOLO_STORE_A(0)
     HOLO_STORE_B(0)
+    HOLO_STAGE_WAIT();
     __syncthreads();
 
     for (int s = 0; s < nstages; ++s) {
         const int chunk = s / C::TAPS, tap = s % C::TAPS;
         const bool has_next = (s + 1) < nstages;
         const bool next_new_chunk = has_next && ((s + 1) % C::TAPS == 0);
-        if (has_next) HOLO_LOAD_B(s + 1)
-        if (next_new_chunk) { HOLO_LOAD_A(chunk + 1) }
+        if (has_next) HOLO_LOAD_B(s + 1, (s + 1) & 1)
+        if (next_new_chunk) { HOLO_LOAD_A(chunk + 1, (chunk + 1) & 1) }
 
         const unsigned char* abuf = lds_a + (chunk & 1) * C::A_BYTES;
         const unsigned char* bbuf = lds_b + (s & 1) * C::B_BYTES;
@@ -209,6 +255,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
         }
         if (has_next) { HOLO_STORE_B((s + 1) & 1) }
         if (next_new_chunk) { HOLO_STORE_A((chunk + 1) & 1) }
+        HOLO_STAGE_WAIT();
         __syncthreads();
     }
 
@@ -275,6 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
 #undef HOLO_STORE_A
 #undef HOLO_LOAD_B
 #undef HOLO_STORE_B
+#undef HOLO_STAGE_WAIT
 
 template <int WM, int WN, bool CONVT>
 static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int batch, int h, int w, int cin,

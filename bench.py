@@ -76,6 +76,17 @@ def cpu_baseline(size, sds, style, sample, seed):
                       f"torch {torch.__version__} CPU"}
 
 
+def pmc_traffic(batch, size):
+    """HBM bytes per conv launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
+    command (profiles/r01_pmc_conv_mfma.json; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  Counters cannot
+    be read from inside the process, so the number is only reported for the workload it was collected on."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_conv_mfma.json")
+    if (batch, size) != (64, 256) or not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["conv_mfma_hbm_bytes_per_launch_avg"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,7 +180,8 @@ def main():
                 calls = sum(r["calls"] for r in conv)
                 ach = fl / (ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                   "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(b, s),
+                                   "algorithmic_bytes_per_launch": round(sum(r["bytes"] for r in conv) / calls),
                                    "kernel": "conv_mfma_f32_kernel (3x3 + transposed, all layers)",
                                    "launches_per_step": calls // args.steps, "avg_launch_ms": round(ms / calls, 4),
                                    "gflop_per_launch": round(fl / calls / 1e9, 3)}

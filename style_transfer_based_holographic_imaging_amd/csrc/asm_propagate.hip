@@ -34,15 +34,18 @@ namespace holo {
 
 constexpr int kRowThreads = 256;
 
-// ---- tables: twiddles exp(-2 pi i m / P) and squared signed frequencies (k/(P px))^2 ------------------
-__global__ void asm_tables_kernel(float2* tw, double* f2, int p, double ppx) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < p) {
-        double s, c;
-        sincospi(-2.0 * (double)m / (double)p, &s, &c);
-        tw[m] = make_float2((float)c, (float)s);
+// ---- tables: packed per-pass twiddles (forward plan, and the inverse plan where it differs) and the squared
+// signed frequencies (k/(P px))^2 -------------------------------------------------------------------------
+constexpr int kTwSlots = 2048;   // float2 entries reserved per table in the workspace
+
+template <int P>
+__global__ void asm_tables_kernel(float2* twf, float2* twi, double* f2, double ppx) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+    fft_fill_twiddles<P, -1>(twf, tid, n);
+    if (!fft_plan_symmetric<P>()) fft_fill_twiddles<P, +1>(twi, tid, n);
+    for (int m = tid; m < P; m += n) {
         // numpy: fx = (arange(2S)/2 - S//2)/(S*px)  ==  signed_bin/(P*px) bit for bit; then fx**2
-        const int ks = m < p / 2 ? m : m - p;
+        const int ks = m < P / 2 ? m : m - P;
         const double f = (double)ks / ppx;
         f2[m] = f * f;
     }
@@ -72,21 +75,21 @@ __device__ __forceinline__ void sincos_f32(float x, float* s, float* c) {
     sincos_poly(r, (int)n & 3, s, c);
 }
 
-__device__ __forceinline__ float2 load_field(const float* __restrict__ in0, const float* __restrict__ in1,
-                                             int in_mode, long off0, long off1, float phase_scale) {
-    if (in_mode == HOLO_ASM_IN_COMPLEX) return reinterpret_cast<const float2*>(in0)[off0];
+__device__ __forceinline__ v2f load_field(const float* __restrict__ in0, const float* __restrict__ in1,
+                                          int in_mode, long off0, long off1, float phase_scale) {
+    if (in_mode == HOLO_ASM_IN_COMPLEX) return reinterpret_cast<const v2f*>(in0)[off0];
     // Forward_model.py:20-22: phase*phase_normalize, then amplitude*exp(1j*phase) in complex64
     const float a = in0[off0];
     const float p = in1[off1] * phase_scale;
     float s, c;
     sincos_f32(p, &s, &c);
-    return make_float2(a * c, a * s);
+    return v2f{a * c, a * s};
 }
 
 // H value for squared frequencies fx2 + fy2: theta = (c/l) * sqrt(max(0, 1 - l^2 (fx^2+fy^2)))
 // (Angular_Spectrum_Method.py:22-29).  float64 up to the reduced angle (theta reaches ~1e4 rad and must be
 // good to ~1e-6 rad), then fp32 sin/cos of the remainder.
-__device__ __forceinline__ float2 transfer_value(double sum_f2, double lam2, double c_over_l) {
+__device__ __forceinline__ v2f transfer_value(double sum_f2, double lam2, double c_over_l) {
     const double g = 1.0 - lam2 * sum_f2;
     double root = 0.0;
     if (g > 0.0) {
@@ -100,38 +103,45 @@ __device__ __forceinline__ float2 transfer_value(double sum_f2, double lam2, dou
     const float r = (fr - m * 0.25f) * 6.28318530717958647692f;        // [-pi/4, pi/4]
     float s, c;
     sincos_poly(r, (int)m & 3, &s, &c);
-    return make_float2(c, s);
+    return v2f{c, s};
 }
+
+// number of LDS twiddle entries a kernel of direction set {fwd, inv} needs
+template <int P>
+__host__ __device__ constexpr int tw_entries_fwd() { return fft_tw_total<P, -1>() > 0 ? fft_tw_total<P, -1>() : 1; }
+template <int P>
+__host__ __device__ constexpr int tw_entries_inv() { return fft_tw_total<P, +1>() > 0 ? fft_tw_total<P, +1>() : 1; }
 
 // ---- K1: pack + pad + row FFT ------------------------------------------------------------------
 template <int P, bool PAD>
 __global__ __launch_bounds__(kRowThreads) void asm_rows_fwd_kernel(
     const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
-    float phase_scale, float2* __restrict__ tbuf, const float2* __restrict__ tw_g, long n_rows) {
+    float phase_scale, v2f* __restrict__ tbuf, const v2f* __restrict__ twf_g, long n_rows) {
     constexpr int S = PAD ? P / 2 : P;
-    constexpr int G = P / 8;               // threads per row, 8 elements each
+    constexpr int G = FftGeom<P>::G;       // lanes per row (<= one wave)
     constexpr int SEQ = kRowThreads / G;   // rows per block
-    constexpr int E = 8;
+    constexpr int E = FftGeom<P>::E;
     constexpr int PITCH = fft_padded_len(P) + 1;
     constexpr int R1 = fft_radix<P, -1>(0);
     constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);
+    constexpr int TWN = tw_entries_fwd<P>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* tw = reinterpret_cast<float2*>(smem_raw);
-    float2* buf = tw + P;
+    v2f* tw = reinterpret_cast<v2f*>(smem_raw);
+    v2f* buf = tw + TWN;
 
     const int tid = threadIdx.x;
     const int seq = tid / G, t = tid % G;
     const long row = (long)blockIdx.x * SEQ + seq;
     const bool valid = row < n_rows;
-    float2* my = buf + seq * PITCH;
-    for (int i = tid; i < P; i += kRowThreads) tw[i] = tw_g[i];
+    v2f* my = buf + seq * PITCH;
+    for (int i = tid; i < TWN; i += kRowThreads) tw[i] = twf_g[i];
 
-    float2 v[E];
+    v2f v[E];
     {
         const long f = valid ? row / S : 0;
         const int y = valid ? (int)(row % S) : 0;
         const long base0 = f * stride0 + (long)y * S, base1 = f * stride1 + (long)y * S;
-        float2 edge0 = make_float2(0.f, 0.f), edge1 = edge0;
+        v2f edge0 = {0.f, 0.f}, edge1 = edge0;
         if (PAD) {  // F.pad(..., mode="replicate") along the row (Angular_Spectrum_Method.py:12)
             edge0 = load_field(in0, in1, in_mode, base0, base1, phase_scale);
             edge1 = load_field(in0, in1, in_mode, base0 + S - 1, base1 + S - 1, phase_scale);
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_fwd_kernel(
     __syncthreads();  // twiddle table
     fft_run<P, G, -1>(v, my, tw, t);
     if (valid) {
-        float2* dst = tbuf + row * P;
+        v2f* dst = tbuf + row * P;
 #pragma unroll
         for (int e = 0; e < E; ++e) dst[fft_elem_index<P, G, RL>(t, e)] = v[e];
     }
@@ -167,45 +177,50 @@ template <int P>
 struct ColCfg {
     // columns per block: 16 x 8 B = one 128-B line per row; fewer only where LDS runs out
     static constexpr int CW = P >= 2048 ? 4 : (P >= 1024 ? 8 : 16);
-    // threads per column: 16 elements per thread from P = 256 up (8 below), i.e. <= 128 VGPRs so that
-    // two 512-thread blocks (16 waves) share a CU; 32 elements/thread measured 1 block/CU and 4x slower
-    static constexpr int G = P >= 256 ? P / 16 : P / 8;
-    static constexpr int THREADS = CW * G;
-    static constexpr int E = P / G;
+    static constexpr int G = FftGeom<P>::G;          // lanes per column: one wave (or part of one) owns a column
+    static constexpr int E = FftGeom<P>::E;
+    static constexpr int THREADS = CW * G;           // 1024 (P=512), 512 (256, 1024), 256 (128, 2048), ...
     static constexpr int PITCH = fft_padded_len(P) + 16 / CW;   // transposed b64 stores spread over the banks
-    static constexpr size_t LDS = (size_t)(P + CW * PITCH) * sizeof(float2);
+    static constexpr int TWN = tw_entries_fwd<P>() + (fft_plan_symmetric<P>() ? 0 : tw_entries_inv<P>());
+    static constexpr size_t LDS = (size_t)(TWN + CW * PITCH) * sizeof(float2);
+    // two blocks per CU: 2*THREADS/64 waves over 4 SIMDs
+    static constexpr int WAVES_PER_SIMD = THREADS >= 128 ? THREADS / 128 : 1;
 };
 
 template <int P, bool PAD>
-__global__ __launch_bounds__(ColCfg<P>::THREADS, (ColCfg<P>::THREADS >= 256 ? 4 : 1)) void asm_cols_kernel(
-    const float2* __restrict__ tbuf, float2* __restrict__ ubuf, const float2* __restrict__ tw_g,
-    const double* __restrict__ f2_g, const double* __restrict__ phase_const, int n_dist, double lam2, double lamb,
-    int ablate) {
+__global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void asm_cols_kernel(
+    const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const v2f* __restrict__ twf_g,
+    const v2f* __restrict__ twi_g, const double* __restrict__ f2_g, const double* __restrict__ phase_const,
+    int n_dist, double lam2, double lamb, int ablate) {
     using C = ColCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int CW = C::CW, G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
     constexpr int R1 = fft_radix<P, -1>(0);
     constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);  // forward's last = inverse's first radix
     static_assert(fft_radix<P, +1>(0) == RL && fft_radix<P, +1>(FftPlan<P>::n - 1) == R1, "plan symmetry");
+    constexpr bool SYM = fft_plan_symmetric<P>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* tw = reinterpret_cast<float2*>(smem_raw);
-    float2* cols = tw + P;
+    v2f* twf = reinterpret_cast<v2f*>(smem_raw);
+    v2f* twi = SYM ? twf : twf + tw_entries_fwd<P>();
+    v2f* cols = twf + C::TWN;
 
     const int tid = threadIdx.x;
     const int fo = blockIdx.y;          // output field = field * n_dist + dist
     const int f = fo / n_dist;
     const int kx0 = blockIdx.x * CW;
-    for (int i = tid; i < P; i += THREADS) tw[i] = tw_g[i];
+    for (int i = tid; i < tw_entries_fwd<P>(); i += THREADS) twf[i] = twf_g[i];
+    if (!SYM)
+        for (int i = tid; i < tw_entries_inv<P>(); i += THREADS) twi[i] = twi_g[i];
     // coalesced read of S rows x CW columns, transposed into per-column sequences (compact: S entries)
-    const float2* src = tbuf + (long)f * S * P + kx0;
+    const v2f* src = tbuf + (long)f * S * P + kx0;
     for (int i = tid; i < S * CW; i += THREADS) {
         const int y = i / CW, cl = i % CW;
         cols[cl * PITCH + fft_pad(y)] = src[(long)y * P + cl];
     }
     __syncthreads();
     const int col = tid / G, t = tid % G;
-    float2* my = cols + col * PITCH;
-    float2 v[E];
+    v2f* my = cols + col * PITCH;
+    v2f v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = fft_elem_index<P, G, R1>(t, e);
@@ -214,26 +229,27 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, (ColCfg<P>::THREADS >= 256 ? 4 
         y = y < 0 ? 0 : (y > S - 1 ? S - 1 : y);
         v[e] = my[fft_pad(y)];
     }
-    if (!(ablate & 2)) fft_run<P, G, -1>(v, my, tw, t);   // spectrum now in registers at ky = fft_elem_index<P,G,RL>(t,e)
+    if (!(ablate & 2)) fft_run<P, G, -1>(v, my, twf, t);   // spectrum in registers at ky = fft_elem_index<P,G,RL>(t,e)
 
-    // transfer function: one value per (column, |ky|), shared through LDS by rows ky and P-ky
-    __syncthreads();                   // all gathers of the last forward pass are done: `cols` is free
+    // transfer function: one value per (column, |ky|), shared through LDS by rows ky and P-ky.  The column's
+    // LDS region is private to its G lanes (one wave or less): wave-local ordering, no block barrier.
+    fft_sync<G>();
     {
         const double c_over_l = phase_const[fo] / lamb;
         const double fx2 = f2_g[kx0 + col];
         for (int m = t; m <= P / 2; m += G)
-            my[m] = (ablate & 1) ? make_float2(1.f, 0.f) : transfer_value(fx2 + f2_g[m], lam2, c_over_l);
+            my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + f2_g[m], lam2, c_over_l);
     }
-    __syncthreads();
+    fft_sync<G>();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int ky = fft_elem_index<P, G, RL>(t, e);
         v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
     }
-    if (!(ablate & 2)) fft_run<P, G, +1>(v, my, tw, t);   // first barrier inside protects the table reads above
+    if (!(ablate & 2)) fft_run<P, G, +1>(v, my, twi, t);
 
     // keep the S centre rows; transpose back through LDS for a coalesced store
-    __syncthreads();
+    fft_sync<G>();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = fft_elem_index<P, G, R1>(t, e);
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, (ColCfg<P>::THREADS >= 256 ? 4 
         if (y >= 0 && y < S) my[fft_pad(y)] = v[e];
     }
     __syncthreads();
-    float2* dst = ubuf + (long)fo * S * P + kx0;
+    v2f* dst = ubuf + (long)fo * S * P + kx0;
     for (int i = tid; i < S * CW; i += THREADS) {
         const int y = i / CW, cl = i % CW;
         dst[(long)y * P + cl] = cols[cl * PITCH + fft_pad(y)];
@@ -251,28 +267,29 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, (ColCfg<P>::THREADS >= 256 ? 4 
 // ---- K3: row IFFT + crop + epilogue ---------------------------------------------------------------
 template <int P, bool PAD>
 __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
-    const float2* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode,
-    long ostride0, long ostride1, const float2* __restrict__ tw_g, long n_rows, float scale) {
+    const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode,
+    long ostride0, long ostride1, const v2f* __restrict__ twi_g, long n_rows, float scale) {
     constexpr int S = PAD ? P / 2 : P;
-    constexpr int G = P / 8;
+    constexpr int G = FftGeom<P>::G;
     constexpr int SEQ = kRowThreads / G;
-    constexpr int E = 8;
+    constexpr int E = FftGeom<P>::E;
     constexpr int PITCH = fft_padded_len(P) + 1;
     constexpr int R1 = fft_radix<P, +1>(0);
     constexpr int RL = fft_radix<P, +1>(FftPlan<P>::n - 1);
+    constexpr int TWN = tw_entries_inv<P>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* tw = reinterpret_cast<float2*>(smem_raw);
-    float2* buf = tw + P;
+    v2f* tw = reinterpret_cast<v2f*>(smem_raw);
+    v2f* buf = tw + TWN;
 
     const int tid = threadIdx.x;
     const int seq = tid / G, t = tid % G;
     const long row = (long)blockIdx.x * SEQ + seq;
     const bool valid = row < n_rows;
-    float2* my = buf + seq * PITCH;
-    for (int i = tid; i < P; i += kRowThreads) tw[i] = tw_g[i];
-    float2 v[E];
+    v2f* my = buf + seq * PITCH;
+    for (int i = tid; i < TWN; i += kRowThreads) tw[i] = twi_g[i];
+    v2f v[E];
     {
-        const float2* src = ubuf + (valid ? row : 0) * P;
+        const v2f* src = ubuf + (valid ? row : 0) * P;
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = src[fft_elem_index<P, G, R1>(t, e)];
     }
@@ -288,9 +305,7 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
             if (PAD && ((r + 1) * 4 <= RL || r * 4 >= 3 * RL)) continue;
             const int i = fft_elem_index<P, G, RL>(t, e);
             const int x = PAD ? i - S / 2 : i;
-            float2 o = v[e];
-            o.x *= scale;
-            o.y *= scale;
+            const v2f o = v[e] * scale;
             const long pix = (long)y * S + x;
             if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
                 out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
                 const float a = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
                 out0[fo * ostride0 + pix] = a * a;
             } else {
-                reinterpret_cast<float2*>(out0)[fo * ostride0 + pix] = o;
+                reinterpret_cast<v2f*>(out0)[fo * ostride0 + pix] = o;
             }
         }
     }
@@ -317,7 +332,7 @@ struct AsmArgs {
     int n_fields, n_dist;
     double ppx, lam2, lamb;
     float phase_scale;
-    float2* tw;
+    float2 *twf, *twi;
     double* f2;
     float2 *tbuf, *ubuf;
     hipStream_t stream;
@@ -328,33 +343,40 @@ template <int P, bool PAD>
 static int launch_asm(const AsmArgs& a) {
     using C = ColCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
-    constexpr int G = P / 8;
+    constexpr int G = FftGeom<P>::G;
     constexpr int SEQ = kRowThreads / G;
-    const size_t row_lds = (size_t)(P + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
+    constexpr bool SYM = fft_plan_symmetric<P>();
+    const size_t row_lds_f = (size_t)(tw_entries_fwd<P>() + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
+    const size_t row_lds_i = (size_t)(tw_entries_inv<P>() + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
     const size_t col_lds = C::LDS;
     static bool attr_done = false;  // idempotent; a race only repeats the call
     if (!attr_done) {
         if (col_lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
-        if (row_lds > 48 * 1024) {
+        if (row_lds_f > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_kernel<P, PAD>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_f);
+        if (row_lds_i > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_kernel<P, PAD>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);
-        }
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
         attr_done = true;
     }
-    hipLaunchKernelGGL(asm_tables_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, a.stream, a.tw, a.f2, P, a.ppx);
+    v2f* twf = reinterpret_cast<v2f*>(a.twf);
+    v2f* twi = SYM ? twf : reinterpret_cast<v2f*>(a.twi);
+    hipLaunchKernelGGL((asm_tables_kernel<P>), dim3(ceil_div(P, 256)), dim3(256), 0, a.stream, a.twf, a.twi, a.f2, a.ppx);
     const long rows_in = (long)a.n_fields * S;
     hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kRowThreads),
-                       row_lds, a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale, a.tbuf, a.tw, rows_in);
+                       row_lds_f, a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale,
+                       reinterpret_cast<v2f*>(a.tbuf), twf, rows_in);
     hipLaunchKernelGGL((asm_cols_kernel<P, PAD>), dim3(P / C::CW, a.n_fields * a.n_dist), dim3(C::THREADS), col_lds,
-                       a.stream, a.tbuf, a.ubuf, a.tw, a.f2, a.phase_const, a.n_dist, a.lam2, a.lamb, a.ablate);
+                       a.stream, reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), twf, twi, a.f2,
+                       a.phase_const, a.n_dist, a.lam2, a.lamb, a.ablate);
     const long rows_out = rows_in * a.n_dist;
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
     hipLaunchKernelGGL((asm_rows_inv_kernel<P, PAD>), dim3((unsigned)((rows_out + SEQ - 1) / SEQ)), dim3(kRowThreads),
-                       row_lds, a.stream, a.ubuf, a.out0, a.out1, a.out_mode, a.os0, a.os1, a.tw, rows_out, scale);
+                       row_lds_i, a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0,
+                       a.os1, twi, rows_out, scale);
     return check_launch("holo_asm_propagate");
 }
 
@@ -363,7 +385,7 @@ static int launch_asm_pad(const AsmArgs& a, bool pad) {
     return pad ? launch_asm<P, true>(a) : launch_asm<P, false>(a);
 }
 
-constexpr size_t kTableBytes = 2048 * sizeof(float2) + 2048 * sizeof(double);
+constexpr size_t kTableBytes = 2 * kTwSlots * sizeof(float2) + 2048 * sizeof(double);
 
 }  // namespace holo
 
@@ -418,8 +440,9 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
     a.lam2 = wavelength * wavelength;
     a.lamb = wavelength;
     a.phase_scale = phase_scale;
-    a.tw = static_cast<float2*>(workspace);
-    a.f2 = reinterpret_cast<double*>(a.tw + 2048);
+    a.twf = static_cast<float2*>(workspace);
+    a.twi = a.twf + kTwSlots;
+    a.f2 = reinterpret_cast<double*>(a.twi + kTwSlots);
     a.tbuf = reinterpret_cast<float2*>(static_cast<unsigned char*>(workspace) + kTableBytes);
     a.ubuf = a.tbuf + (size_t)n_fields * s * p;
     a.stream = as_stream(stream);

@@ -50,7 +50,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.holo_asm_propagate(fake, None, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 64, 1, 5e-7, 1e-6, 1.0,
                                   fake, 1 << 30, None) == 1                                      # missing phase
     assert lib.holo_adain_apply_f32(fake, fake, fake, fake, fake, 0, 1.5, fake, 1, 4, 64, None) == 1  # alpha
-    assert lib.holo_asm_workspace_bytes(2, 3, 64, 1) == 2048 * 8 + 2048 * 8 + 64 * 128 * 8 * (2 + 6)
+    assert lib.holo_asm_workspace_bytes(2, 3, 64, 1) == 3 * 2048 * 8 + 64 * 128 * 8 * (2 + 6)
     assert lib.holo_conv3x3_packed_elems(128, 64) == 9 * 64 * 128
 
 

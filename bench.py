@@ -87,6 +87,15 @@ def pmc_traffic(batch, size):
         return round(json.load(f)["conv_mfma_hbm_bytes_per_launch_avg"])
 
 
+def pmc_traffic_asm(batch, size):
+    """HBM bytes per propagator call from profiles/r01_pmc_asm_propagate.json (same provenance as pmc_traffic)."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_asm_propagate.json")
+    if (batch, size) != (64, 256) or not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["hbm_bytes_per_call"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +198,8 @@ def main():
                 r = summ["holo_asm_propagate"]
                 gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9
                 out["roofline_propagator"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                              "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                              "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": pmc_traffic_asm(b, s),
+                                              "algorithmic_bytes_per_call": round(r["bytes"] / r["calls"]),
                                               "kernel": "asm_rows_fwd + asm_cols + asm_rows_inv (80*S^2 B per field)",
                                               "avg_call_ms": round(r["ms"] / r["calls"], 4)}
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(summ.items())}

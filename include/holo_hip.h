@@ -31,7 +31,7 @@ extern "C" {
 /* error codes */
 #define HOLO_OK 0
 #define HOLO_ERR_ARG 1        /* bad pointer / shape / mode */
-#define HOLO_ERR_UNSUPPORTED 2 /* valid request the kernels do not cover (e.g. non power-of-two FFT side) */
+#define HOLO_ERR_UNSUPPORTED 2 /* valid request the kernels do not cover (e.g. transform side > 4096) */
 #define HOLO_ERR_WORKSPACE 3  /* workspace too small */
 #define HOLO_ERR_LAUNCH 4     /* hipGetLastError() after a launch */
 
@@ -123,7 +123,8 @@ size_t holo_asm_workspace_bytes(int n_fields, int n_dist, int s, int zero_paddin
  * in*_stride / out*_stride: elements (floats, or complex64 for the complex modes) between
  * consecutive fields, so strided views such as g_t[:, :1] (net.py:250-251) need no copy.
  * zero_padding != 0: replicate-pad to P = 2S (Angular_Spectrum_Method.py:11-14); else P = S.
- * P must be a power of two, 8 <= P <= 2048. */
+ * P a power of two in [16, 2048]: fused in-LDS FFT kernels.  Any other 2 <= P <= 4096 (zero_padding needs an
+ * even S, as in the reference): direct-DFT kernels, O(P^3) per field — correct, not fast. */
 int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_stride, long in1_stride,
                        void* out0, void* out1, int out_mode, long out0_stride, long out1_stride,
                        const double* phase_const, int n_fields, int n_dist, int s, int zero_padding,

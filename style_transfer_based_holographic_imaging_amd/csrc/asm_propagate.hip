@@ -36,7 +36,7 @@ constexpr int kRowThreads = 256;
 
 // ---- tables: packed per-pass twiddles (forward plan, and the inverse plan where it differs) and the squared
 // signed frequencies (k/(P px))^2 -------------------------------------------------------------------------
-constexpr int kTwSlots = 2048;   // float2 entries reserved per table in the workspace
+constexpr int kTwSlots = 4096;   // float2 entries reserved per table in the workspace (generic path: P <= 4096)
 
 template <int P>
 __global__ void asm_tables_kernel(float2* twf, float2* twi, double* f2, double ppx) {
@@ -385,7 +385,141 @@ static int launch_asm_pad(const AsmArgs& a, bool pad) {
     return pad ? launch_asm<P, true>(a) : launch_asm<P, false>(a);
 }
 
-constexpr size_t kTableBytes = 2 * kTwSlots * sizeof(float2) + 2048 * sizeof(double);
+// ---- generic sizes: direct DFT ------------------------------------------------------------------------------
+// Any FFT side 2 <= P <= 4096 that is not a power of two in [16, 2048] (e.g. the 40x40 output of a 36x36
+// hologram, P = 80): the same three-stage decomposition with O(P) direct sums per output instead of the
+// Stockham passes.  A correctness path, not a fast one (O(P^3) per field); twiddles W_P^m from a float64-
+// rounded table indexed by (c*k) mod P, so the accuracy matches the FFT path.
+__global__ void asm_generic_tables_kernel(float2* tw, double* f2, int p, double ppx) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= p) return;
+    double s, c;
+    sincospi(-2.0 * (double)m / (double)p, &s, &c);
+    tw[m] = make_float2((float)c, (float)s);
+    // fftshift puts bin k at index (k + p/2) mod p and G is sampled at (index - p/2)/(p*px): signed bin
+    const int ks = m < p - p / 2 ? m : m - p;
+    const double f = (double)ks / ppx;
+    f2[m] = f * f;
+}
+
+// one block per distinct row: T[row][k] = sum_c x[c] W^{ck}
+__global__ __launch_bounds__(256) void asm_generic_rows_fwd_kernel(
+    const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
+    float phase_scale, v2f* __restrict__ tbuf, const v2f* __restrict__ tw, int p, int s, int pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* x = reinterpret_cast<v2f*>(smem_raw);
+    const long row = blockIdx.x;
+    const long f = row / s;
+    const int y = (int)(row % s);
+    for (int c = threadIdx.x; c < p; c += 256) {
+        int col = c - pad;
+        col = col < 0 ? 0 : (col > s - 1 ? s - 1 : col);
+        const long pix = (long)y * s + col;
+        x[c] = load_field(in0, in1, in_mode, f * stride0 + pix, f * stride1 + pix, phase_scale);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < p; k += 256) {
+        v2f acc = {0.f, 0.f};
+        int m = 0;
+        for (int c = 0; c < p; ++c) {
+            acc += cmul(x[c], tw[m]);
+            m += k;
+            if (m >= p) m -= p;
+        }
+        tbuf[row * p + k] = acc;
+    }
+}
+
+// one block per (output field, column kx): column DFT of the replicate-padded column, H, inverse DFT of the kept rows
+__global__ __launch_bounds__(256) void asm_generic_cols_kernel(
+    const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const v2f* __restrict__ tw, const double* __restrict__ f2,
+    const double* __restrict__ phase_const, int n_dist, int p, int s, int pad, double lam2, double lamb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* x = reinterpret_cast<v2f*>(smem_raw);   // p inputs, then p spectrum values
+    v2f* spec = x + p;
+    const int kx = blockIdx.x, fo = blockIdx.y, f = fo / n_dist;
+    for (int r = threadIdx.x; r < p; r += 256) {
+        int y = r - pad;
+        y = y < 0 ? 0 : (y > s - 1 ? s - 1 : y);
+        x[r] = tbuf[((long)f * s + y) * p + kx];
+    }
+    __syncthreads();
+    const double c_over_l = phase_const[fo] / lamb;
+    const double fx2 = f2[kx];
+    for (int ky = threadIdx.x; ky < p; ky += 256) {
+        v2f acc = {0.f, 0.f};
+        int m = 0;
+        for (int r = 0; r < p; ++r) {
+            acc += cmul(x[r], tw[m]);
+            m += ky;
+            if (m >= p) m -= p;
+        }
+        spec[ky] = cmul(acc, transfer_value(fx2 + f2[ky], lam2, c_over_l));
+    }
+    __syncthreads();
+    for (int y = threadIdx.x; y < s; y += 256) {
+        const int r = y + pad;
+        v2f acc = {0.f, 0.f};
+        int m = 0;
+        for (int ky = 0; ky < p; ++ky) {
+            acc += cmul_conj(spec[ky], tw[m]);
+            m += r;
+            if (m >= p) m -= p;
+        }
+        ubuf[((long)fo * s + y) * p + kx] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void asm_generic_rows_inv_kernel(
+    const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode, long ostride0,
+    long ostride1, const v2f* __restrict__ tw, int p, int s, int pad, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* x = reinterpret_cast<v2f*>(smem_raw);
+    const long row = blockIdx.x;
+    const long fo = row / s;
+    const int y = (int)(row % s);
+    for (int k = threadIdx.x; k < p; k += 256) x[k] = ubuf[row * p + k];
+    __syncthreads();
+    for (int xo = threadIdx.x; xo < s; xo += 256) {
+        const int c = xo + pad;
+        v2f acc = {0.f, 0.f};
+        int m = 0;
+        for (int k = 0; k < p; ++k) {
+            acc += cmul_conj(x[k], tw[m]);
+            m += c;
+            if (m >= p) m -= p;
+        }
+        const v2f o = acc * scale;
+        const long pix = (long)y * s + xo;
+        if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
+            out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
+            out1[fo * ostride1 + pix] = atan2f(o.y, o.x);
+        } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
+            const float a = sqrtf(o.x * o.x + o.y * o.y);
+            out0[fo * ostride0 + pix] = a * a;
+        } else {
+            reinterpret_cast<v2f*>(out0)[fo * ostride0 + pix] = o;
+        }
+    }
+}
+
+static int launch_asm_generic(const AsmArgs& a, int p, int s, int pad) {
+    hipLaunchKernelGGL(asm_generic_tables_kernel, dim3(ceil_div(p, 256)), dim3(256), 0, a.stream, a.twf, a.f2, p, a.ppx);
+    const v2f* tw = reinterpret_cast<const v2f*>(a.twf);
+    const long rows_in = (long)a.n_fields * s;
+    hipLaunchKernelGGL(asm_generic_rows_fwd_kernel, dim3((unsigned)rows_in), dim3(256), (size_t)p * sizeof(float2), a.stream,
+                       a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf), tw, p, s, pad);
+    hipLaunchKernelGGL(asm_generic_cols_kernel, dim3(p, a.n_fields * a.n_dist), dim3(256), (size_t)2 * p * sizeof(float2),
+                       a.stream, reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), tw, a.f2, a.phase_const,
+                       a.n_dist, p, s, pad, a.lam2, a.lamb);
+    const float scale = (float)(1.0 / ((double)p * (double)p));
+    hipLaunchKernelGGL(asm_generic_rows_inv_kernel, dim3((unsigned)(rows_in * a.n_dist)), dim3(256), (size_t)p * sizeof(float2),
+                       a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0, a.os1, tw, p, s, pad,
+                       scale);
+    return check_launch("holo_asm_propagate (generic size)");
+}
+
+constexpr size_t kTableBytes = 2 * kTwSlots * sizeof(float2) + kTwSlots * sizeof(double);
 
 }  // namespace holo
 
@@ -415,10 +549,12 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
     HOLO_REQUIRE((long)n_fields * n_dist <= 65535, HOLO_ERR_UNSUPPORTED,
                  "holo_asm_propagate: at most 65535 output fields per call (got %ld)", (long)n_fields * n_dist);
     HOLO_REQUIRE(wavelength > 0 && pixel_size > 0, HOLO_ERR_ARG, "holo_asm_propagate: wavelength/pixel_size <= 0");
+    // Angular_Spectrum_Method.py:12-14: pad S//2 per side but sample 2S frequencies: odd S cannot be padded there either
+    HOLO_REQUIRE(!zero_padding || s % 2 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_asm_propagate: zero_padding needs an even field side (got %d), as in the reference", s);
     const int p = zero_padding ? 2 * s : s;
-    HOLO_REQUIRE((p & (p - 1)) == 0 && p >= 16 && p <= 2048, HOLO_ERR_UNSUPPORTED,
-                 "holo_asm_propagate: FFT side %d (S=%d, zero_padding=%d) must be a power of two in [16,2048]", p, s,
-                 zero_padding);
+    HOLO_REQUIRE(p >= 2 && p <= 4096, HOLO_ERR_UNSUPPORTED, "holo_asm_propagate: transform side %d outside [2,4096]", p);
+    const bool fast = (p & (p - 1)) == 0 && p >= 16 && p <= 2048;
     HOLO_REQUIRE(workspace_bytes >= holo_asm_workspace_bytes(n_fields, n_dist, s, zero_padding), HOLO_ERR_WORKSPACE,
                  "holo_asm_propagate: workspace %zu < required %zu", workspace_bytes,
                  holo_asm_workspace_bytes(n_fields, n_dist, s, zero_padding));
@@ -451,6 +587,7 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
         a.ablate = env ? atoi(env) : 0;
     }
     const bool pad = zero_padding != 0;
+    if (!fast) return launch_asm_generic(a, p, s, pad ? s / 2 : 0);
     switch (p) {
         case 16: return launch_asm_pad<16>(a, pad);
         case 32: return launch_asm_pad<32>(a, pad);

@@ -27,6 +27,9 @@
 //   C/D layout: m = (reg&3) + 8*(reg>>2) + 4*(lane>>5), n = lane&31
 #include "common.h"
 
+#ifndef HOLO_CONV_SETPRIO
+#define HOLO_CONV_SETPRIO 0
+#endif
 #ifndef HOLO_CONV_GLDS
 #define HOLO_CONV_GLDS 1   // 1: LDS-DMA staging (global_load_lds_dwordx4); 0: register staging
 #endif
@@ -223,6 +226,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
             const int q = (lpy + 2 * mt + dy) * C::HW + lpx + dx;
             a_off[mt] = swz(q, hsel);
         }
+#if HOLO_CONV_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float4 av[2], bv[2];
@@ -243,6 +249,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
                 }
             }
         }
+#if HOLO_CONV_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (FOLD && tap == C::TAPS - 1) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)

@@ -99,6 +99,11 @@ def test_edge_cases(env, golden, mnist_style):
         assert a36.shape == (2, 1, 40, 40)
         assert rel_err(a36.cpu(), g["odd_amp"]) < TOL and rel_err(p36.cpu(), g["odd_ph"]) < TOL
         assert rel_err(d36.cpu(), g["odd_dist"]) < TOL
+        # ... and the 40x40 result still back-propagates (transform side 80: generic-size propagator kernels)
+        from hip_helpers import cplx_rel, orc
+        fld = env["hg"](a36, p36, -torch.full((2, 1, 1, 1), 0.2, device=dev), complex_number=True)
+        ref = orc.holo_generator(orc.HoloParams(), a36.cpu(), p36.cpu(), -torch.full((2, 1, 1, 1), 0.2), complex_number=True)
+        assert cplx_rel(fld, ref) < 1e-5
         for name in ("polystyrene_bead", "red_blood_cell"):
             s2 = torch.load(os.path.join(REPO, "style_representation", name, "style_vector.pt"), map_location="cpu").float()
             a_s, p_s, d_s = network.field_retrieval(c32.to(dev), s2.to(dev), 1.0, True)

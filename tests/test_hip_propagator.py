@@ -116,8 +116,31 @@ def test_sweep_matches_repeat_idiom(hg, dev):
         assert torch.equal(a_s[:, k:k + 1], a_k) and torch.equal(p_s[:, k:k + 1], p_k)
 
 
+@pytest.mark.parametrize("s,b,padded", [(40, 2, True), (100, 2, True), (36, 3, False), (25, 2, False), (6, 1, True)])
+def test_generic_sizes_against_oracle(hg, dev, s, b, padded):
+    """Transform sides that are not powers of two (80, 200, 36, 25, 12) take the direct-DFT kernels."""
+    from hip_helpers import cplx_rel, orc
+    from utils.Angular_Spectrum_Method import ASM
+    g = torch.Generator().manual_seed(s)
+    amp = torch.rand(b, 1, s, s, generator=g) + 0.3
+    ph = (torch.rand(b, 1, s, s, generator=g) - 0.5) * 5.0
+    d = torch.tensor([0.3, -0.45, 0.7][:b]).view(-1, 1, 1, 1)
+    if padded:
+        ref = orc.holo_generator(orc.HoloParams(), amp, ph, d, complex_number=True)
+        got = hg(amp.to(dev), ph.to(dev), d.to(dev), complex_number=True)
+        a_o, p_o = hg(amp.to(dev), ph.to(dev), d.to(dev), return_field=True)
+        assert cplx_rel(torch.polar(a_o, p_o), ref) < 1e-5
+    else:
+        o_low = amp * torch.exp(1j * ph)
+        ref = orc.asm(o_low, 532e-9, d * 1e-3, 1.5e-6, zero_padding=False)
+        got = ASM(o_low.to(dev), 532e-9, (d * 1e-3).to(dev), 1.5e-6, zero_padding=False)
+    assert got.shape == ref.shape and cplx_rel(got, ref) < 1e-5
+
+
 def test_rejects_unsupported_sizes(hg, dev):
-    with pytest.raises(RuntimeError, match="power of two"):
-        hg(torch.ones(1, 1, 40, 40, device=dev), torch.zeros(1, 1, 40, 40, device=dev), 0.3)
+    with pytest.raises(RuntimeError, match="even field side"):
+        hg(torch.ones(1, 1, 41, 41, device=dev), torch.zeros(1, 1, 41, 41, device=dev), 0.3)
+    with pytest.raises(RuntimeError, match="outside"):
+        hg(torch.ones(1, 1, 2050, 2050, device=dev), torch.zeros(1, 1, 2050, 2050, device=dev), 0.3)
     with pytest.raises(RuntimeError, match="ROCm device"):
         hg(torch.ones(1, 1, 32, 32), torch.zeros(1, 1, 32, 32), 0.3)

@@ -42,15 +42,18 @@ def test_argument_validation_needs_no_gpu():
     assert b"reflection padding" in lib.holo_last_error()
     assert lib.holo_conv3x3_f32(fake, fake, fake, fake, 1, 4, 4, 24, 64, 1, 0, None) == 2       # Cin % 16
     assert lib.holo_conv3x3_f32(fake, fake, fake, fake, 1, 4, 4, 16, 64, 0, 1, None) == 2       # pool without relu
-    assert lib.holo_asm_propagate(fake, fake, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 40, 1, 5e-7, 1e-6, 1.0,
-                                  fake, 1 << 30, None) == 2                                      # P = 80
-    assert b"power of two" in lib.holo_last_error()
+    assert lib.holo_asm_propagate(fake, fake, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 4000, 1, 5e-7, 1e-6, 1.0,
+                                  fake, 1 << 40, None) == 2                                      # P = 8000
+    assert b"outside [2,4096]" in lib.holo_last_error()
+    assert lib.holo_asm_propagate(fake, fake, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 41, 1, 5e-7, 1e-6, 1.0,
+                                  fake, 1 << 30, None) == 2                                      # odd S, padded
+    assert b"even field side" in lib.holo_last_error()
     assert lib.holo_asm_propagate(fake, fake, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 64, 1, 5e-7, 1e-6, 1.0,
                                   fake, 16, None) == 3                                           # workspace
     assert lib.holo_asm_propagate(fake, None, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 64, 1, 5e-7, 1e-6, 1.0,
                                   fake, 1 << 30, None) == 1                                      # missing phase
     assert lib.holo_adain_apply_f32(fake, fake, fake, fake, fake, 0, 1.5, fake, 1, 4, 64, None) == 1  # alpha
-    assert lib.holo_asm_workspace_bytes(2, 3, 64, 1) == 3 * 2048 * 8 + 64 * 128 * 8 * (2 + 6)
+    assert lib.holo_asm_workspace_bytes(2, 3, 64, 1) == 3 * 4096 * 8 + 64 * 128 * 8 * (2 + 6)
     assert lib.holo_conv3x3_packed_elems(128, 64) == 9 * 64 * 128
 
 

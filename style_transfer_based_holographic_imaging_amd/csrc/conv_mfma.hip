@@ -13,7 +13,7 @@
 // Data movement
 //   * activations are NHWC: a halo pixel's 16-channel chunk is 64 contiguous bytes (4 x 16-B units)
 //   * per 16-channel K chunk the (PR+2) x 18 halo is staged ONCE in LDS (reflection resolved by the
-//     loader) and reused by all 9 taps; weights are staged per (tap, chunk) as [co][16]
+//     loader) and reused by all 9 taps; weights are staged per (chunk, tap) as [co][16]
 //   * LDS rows are 64 B per pixel / per output channel; the 16-B unit index is XOR-swizzled with
 //     bits 2..3 of the row so that the ds_read_b128 of 32 rows spreads over the banks
 //   * a lane's ds_read_b128 returns 4 consecutive channels: lanes 0-31 read unit 2j, lanes 32-63 unit
@@ -27,6 +27,9 @@
 //   C/D layout: m = (reg&3) + 8*(reg>>2) + 4*(lane>>5), n = lane&31
 #include "common.h"
 
+#ifndef HOLO_CONV_MINWAVES
+#define HOLO_CONV_MINWAVES 2   // minimum waves per SIMD the register allocator must allow
+#endif
 #ifndef HOLO_CONV_SETPRIO
 #define HOLO_CONV_SETPRIO 0
 #endif
@@ -63,7 +66,7 @@ struct ConvCfg {
 __device__ __forceinline__ int swz(int row, int unit) { return row * 64 + ((unit ^ ((row >> 2) & 3)) << 4); }
 
 template <int WM, int WN, bool CONVT>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
+__global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f32_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, int H, int W, int Cin, int Cout, int N, int tiles_x, int tiles_y, int relu, int pool) {
     using C = ConvCfg<WM, WN, CONVT>;
@@ -84,7 +87,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
     const int n0 = nb * C::TN;
     const float* __restrict__ ximg = x + (size_t)img * H * W * Cin;
     const int nchunks = Cin / kKC;
-    const int nstages = nchunks * C::TAPS;
 
     // ---- staging plans (fixed per block) -------------------------------------------------------
     // 16-byte unit u = tid + r*THREADS of the LDS image holds unit (u&3) ^ swizzle of halo pixel / output
@@ -131,13 +133,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
             HOLO_GLDS16(ximg + a_src[r] + (chunk_) * kKC,                                                 \
                         (buf_) * C::A_BYTES + r * C::THREADS * 16 + wave_base)                           \
     }
-#define HOLO_LOAD_B(stage_, buf_)                                                                         \
+#define HOLO_LOAD_B(wsrc_, buf_)                                                                          \
     {                                                                                                     \
-        const int chunk_b = (stage_) / C::TAPS, tap_b = (stage_) % C::TAPS;                               \
-        const float* __restrict__ wsrc = wp + ((size_t)(tap_b * nchunks + chunk_b) * N + n0) * kKC;       \
         _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                         \
             if (tid + r * C::THREADS < C::B_UNITS)                                                        \
-                HOLO_GLDS16(wsrc + b_src[r], 2 * C::A_BYTES + (buf_) * C::B_BYTES + r * C::THREADS * 16 + wave_base) \
+                HOLO_GLDS16((wsrc_) + b_src[r], 2 * C::A_BYTES + (buf_) * C::B_BYTES + r * C::THREADS * 16 + wave_base) \
         }                                                                                                 \
     }
 #define HOLO_STORE_A(buf_)
@@ -160,12 +160,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
         if (tid + r * C::THREADS < C::A_UNITS)                                                            \
             *reinterpret_cast<float4*>(lds_a + (buf_) * C::A_BYTES + (tid + r * C::THREADS) * 16) = a_reg[r]; \
     }
-#define HOLO_LOAD_B(stage_, buf_)                                                                         \
+#define HOLO_LOAD_B(wsrc_, buf_)                                                                          \
     {                                                                                                     \
-        const int chunk_b = (stage_) / C::TAPS, tap_b = (stage_) % C::TAPS;                               \
-        const float* __restrict__ wsrc = wp + ((size_t)(tap_b * nchunks + chunk_b) * N + n0) * kKC;       \
         _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                         \
-            if (tid + r * C::THREADS < C::B_UNITS) b_reg[r] = *reinterpret_cast<const float4*>(wsrc + b_src[r]); \
+            if (tid + r * C::THREADS < C::B_UNITS) b_reg[r] = *reinterpret_cast<const float4*>((wsrc_) + b_src[r]); \
         }                                                                                                 \
     }
 #define HOLO_STORE_B(buf_)                                                                                \
@@ -198,74 +196,85 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_f32_kernel(
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc[mt][nt][r] = 0.0f;
+                acc[mt][nt][r] = 0.0f;   // live only for the transposed conv (no fold); dead otherwise
                 tot[mt][nt][r] = 0.0f;
             }
 
-    // ---- prologue ----------------------------------------------------------------------------------------
+    // ---- main loop ------------------------------------------------------------------------------------------
+    // Stages run chunk-major with the TAPS stages of a chunk unrolled at compile time: tap offsets are
+    // constants, the packed-weight pointer simply advances by one [N][16] tile per stage (layout
+    // [chunk][tap][N][16]) and the two LDS buffer parities are toggled, so a stage carries no div/mod or
+    // 64-bit multiply.  With the per-chunk fold the first MFMA of a chunk takes C = 0 (an inline constant):
+    // the accumulators are never zeroed.
+    const float* __restrict__ wsrc = wp + (size_t)n0 * kKC;
+    const size_t w_stage = (size_t)N * kKC;
     HOLO_LOAD_A(0, 0)
-    HOLO_LOAD_B(0, 0)
+    HOLO_LOAD_B(wsrc, 0)
     HOLO_STORE_A(0)
     HOLO_STORE_B(0)
     HOLO_STAGE_WAIT();
     __syncthreads();
 
-    for (int s = 0; s < nstages; ++s) {
-        const int chunk = s / C::TAPS, tap = s % C::TAPS;
-        const bool has_next = (s + 1) < nstages;
-        const bool next_new_chunk = has_next && ((s + 1) % C::TAPS == 0);
-        if (has_next) HOLO_LOAD_B(s + 1, (s + 1) & 1)
-        if (next_new_chunk) { HOLO_LOAD_A(chunk + 1, (chunk + 1) & 1) }
+    int apar = 0, bpar = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more_chunks = chunk + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < C::TAPS; ++tap) {
+            constexpr int kLast = C::TAPS - 1;
+            const bool has_next = tap != kLast || more_chunks;
+            if (has_next) {
+                wsrc += w_stage;
+                HOLO_LOAD_B(wsrc, bpar ^ 1)
+            }
+            if (tap == kLast && more_chunks) { HOLO_LOAD_A(chunk + 1, apar ^ 1) }
 
-        const unsigned char* abuf = lds_a + (chunk & 1) * C::A_BYTES;
-        const unsigned char* bbuf = lds_b + (s & 1) * C::B_BYTES;
-        const int dy = CONVT ? 0 : tap / 3, dx = CONVT ? 0 : tap % 3;
-        int a_off[2];
+            const unsigned char* abuf = lds_a + apar * C::A_BYTES;
+            const unsigned char* bbuf = lds_b + bpar * C::B_BYTES;
+            const int dy = CONVT ? 0 : tap / 3, dx = CONVT ? 0 : tap % 3;   // constants after unrolling
+            int a_off[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int q = (lpy + 2 * mt + dy) * C::HW + lpx + dx;
-            a_off[mt] = swz(q, hsel);
-        }
-#if HOLO_CONV_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+            for (int mt = 0; mt < 2; ++mt) {
+                const int q = (lpy + 2 * mt + dy) * C::HW + lpx + dx;
+                a_off[mt] = swz(q, hsel);
+            }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float4 av[2], bv[2];
+            for (int j = 0; j < 2; ++j) {
+                float4 av[2], bv[2];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const float4*>(abuf + (a_off[mt] ^ (j << 5)));
+                for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const float4*>(abuf + (a_off[mt] ^ (j << 5)));
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bbuf + (b_off[nt] ^ (j << 5)));
+                for (int nt = 0; nt < 2; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bbuf + (b_off[nt] ^ (j << 5)));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const float a = k == 0 ? av[mt].x : (k == 1 ? av[mt].y : (k == 2 ? av[mt].z : av[mt].w));
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const float a = k == 0 ? av[mt].x : (k == 1 ? av[mt].y : (k == 2 ? av[mt].z : av[mt].w));
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const float b = k == 0 ? bv[nt].x : (k == 1 ? bv[nt].y : (k == 2 ? bv[nt].z : bv[nt].w));
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const float b = k == 0 ? bv[nt].x : (k == 1 ? bv[nt].y : (k == 2 ? bv[nt].z : bv[nt].w));
+                            if (FOLD && tap == 0 && j == 0 && k == 0) {
+                                const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, zero, 0, 0, 0);
+                            } else {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
+            if (FOLD && tap == kLast) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) tot[mt][nt] += acc[mt][nt];
+            }
+            if (has_next) { HOLO_STORE_B(bpar ^ 1) }
+            if (tap == kLast && more_chunks) { HOLO_STORE_A(apar ^ 1) }
+            HOLO_STAGE_WAIT();
+            __syncthreads();
+            bpar ^= 1;
         }
-#if HOLO_CONV_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        if (FOLD && tap == C::TAPS - 1) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    tot[mt][nt] += acc[mt][nt];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-                }
-        }
-        if (has_next) { HOLO_STORE_B((s + 1) & 1) }
-        if (next_new_chunk) { HOLO_STORE_A((chunk + 1) & 1) }
-        HOLO_STAGE_WAIT();
-        __syncthreads();
+        apar ^= 1;
     }
 
     // ---- epilogue: bias, ReLU, optional 2x2 max-pool, NHWC store ------------------------------------------
@@ -362,11 +371,10 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
     long r = i / kKC;
     const int co = (int)(r % cout);
     r /= cout;
-    const int nch = cin / kKC;
-    const int chunk = (int)(r % nch);
-    const int tap = (int)(r / nch);
+    const int tap = (int)(r % 9);
+    const int chunk = (int)(r / 9);
     const int ci = chunk * kKC + k;
-    out[i] = w[((long)co * cin + ci) * 9 + tap];  // OIHW, tap = ky*3+kx
+    out[i] = w[((long)co * cin + ci) * 9 + tap];  // OIHW, tap = ky*3+kx; packed [chunk][tap][co][16]
 }
 
 __global__ void pack_convt2x2_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout) {

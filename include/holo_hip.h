@@ -43,7 +43,8 @@ const char* holo_target_arch(void);
 /* ------------------------------------------------------------------------------------------
  * Weight packing (done once per module; reference keeps OIHW / IOHW tensors, net.py:33-130)
  * ---------------------------------------------------------------------------------------- */
-/* Conv2d weight (Cout,Cin,3,3) -> [Cin/16][tap=ky*3+kx][Cout][16] fp32, Cin % 16 == 0 */
+/* Conv2d weight (Cout,Cin,3,3) -> [Cin/KC][tap=ky*3+kx][Cout][KC] fp32, Cin % 16 == 0; KC (16 or 32 channels per
+ * pipeline stage) is chosen by the library from (Cin, Cout): pack and holo_conv3x3_f32 always agree */
 int holo_pack_conv3x3_weight_f32(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
 size_t holo_conv3x3_packed_elems(int cout, int cin);
 /* ConvTranspose2d weight (Cin,Cout,2,2) -> [Cin/16][q=dy*2+dx][Cout][16] fp32, Cin % 16 == 0 */

@@ -41,11 +41,15 @@ namespace holo {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kKC = 16;  // channels per K chunk
+constexpr int kKC = 16;  // smallest K chunk (channels); weights/activations need Cin % 16 == 0
 constexpr int kPW = 16;  // patch width in pixels
 
-template <int WM, int WN, bool CONVT>
+// KC = channels per stage: 16 (one 64-B LDS row per pixel / output channel) or 32 (128-B rows, twice the MFMAs
+// between two barriers; used where the deeper buffers still leave two blocks per CU)
+template <int WM, int WN, bool CONVT, int KC>
 struct ConvCfg {
+    static constexpr int UPR = KC / 4;   // 16-byte units per LDS row
+    static constexpr int ROWB = KC * 4;  // bytes per LDS row
     static constexpr int PR = WM * 4;  // patch rows
     static constexpr int TN = WN * 64;
     static constexpr int HALO = CONVT ? 0 : 1;
@@ -53,23 +57,31 @@ struct ConvCfg {
     static constexpr int HW = kPW + 2 * HALO;
     static constexpr int TAPS = CONVT ? 1 : 9;
     static constexpr int THREADS = WM * WN * 64;
-    static constexpr int A_UNITS = HR * HW * 4;  // 16-byte units per chunk
+    static constexpr int A_UNITS = HR * HW * UPR;  // 16-byte units per chunk
     static constexpr int A_ROUNDS = (A_UNITS + THREADS - 1) / THREADS;
-    static constexpr int B_UNITS = TN * 4;
+    static constexpr int B_UNITS = TN * UPR;
     static constexpr int B_ROUNDS = (B_UNITS + THREADS - 1) / THREADS;
-    static constexpr int A_BYTES = HR * HW * 64;
-    static constexpr int B_BYTES = TN * 64;
+    static constexpr int A_BYTES = HR * HW * ROWB;
+    static constexpr int B_BYTES = TN * ROWB;
     static constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;
     // A is re-staged every chunk; for CONVT every stage is a new chunk
 };
 
-__device__ __forceinline__ int swz(int row, int unit) { return row * 64 + ((unit ^ ((row >> 2) & 3)) << 4); }
+// byte offset of 16-byte unit `unit` of LDS row `row`: the unit index is XOR-swizzled with row bits so that the
+// ds_read_b128 of 16 consecutive rows at one unit covers all 64 banks (64-B rows: 4 rows per 256-B bank row,
+// swizzle by row>>2; 128-B rows: 2 rows per bank row, swizzle by row>>1)
+template <int KC>
+__device__ __forceinline__ int swz_unit(int row, int unit) {
+    return KC == 16 ? (unit ^ ((row >> 2) & 3)) : (unit ^ ((row >> 1) & 7));
+}
+template <int KC>
+__device__ __forceinline__ int swz(int row, int unit) { return row * (KC * 4) + (swz_unit<KC>(row, unit) << 4); }
 
-template <int WM, int WN, bool CONVT>
+template <int WM, int WN, bool CONVT, int KC>
 __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f32_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, int H, int W, int Cin, int Cout, int N, int tiles_x, int tiles_y, int relu, int pool) {
-    using C = ConvCfg<WM, WN, CONVT>;
+    using C = ConvCfg<WM, WN, CONVT, KC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_a = smem;                   // [2][A_BYTES]
     unsigned char* lds_b = smem + 2 * C::A_BYTES;  // [2][B_BYTES]
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
     const int y0 = ty * C::PR, x0 = tx * kPW;
     const int n0 = nb * C::TN;
     const float* __restrict__ ximg = x + (size_t)img * H * W * Cin;
-    const int nchunks = Cin / kKC;
+    const int nchunks = Cin / KC;
 
     // ---- staging plans (fixed per block) -------------------------------------------------------
     // 16-byte unit u = tid + r*THREADS of the LDS image holds unit (u&3) ^ swizzle of halo pixel / output
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #pragma unroll
     for (int r = 0; r < C::A_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
-        const int q = u >> 2, c = (u & 3) ^ ((q >> 2) & 3);
+        const int q = u / C::UPR, c = swz_unit<KC>(q, u % C::UPR);
         const int hy = q / C::HW, hx = q % C::HW;
         const int ry = reflect1(y0 - C::HALO + hy, H);
         const int rx = reflect1(x0 - C::HALO + hx, W);
@@ -106,8 +118,8 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #pragma unroll
     for (int r = 0; r < C::B_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
-        const int co = u >> 2, c = (u & 3) ^ ((co >> 2) & 3);
-        b_src[r] = co * kKC + 4 * c;
+        const int co = u / C::UPR, c = swz_unit<KC>(co, u % C::UPR);
+        b_src[r] = co * KC + 4 * c;
     }
 #if HOLO_CONV_GLDS
     // global_load_lds_dwordx4: no staging VGPRs, no ds_write; completion = s_waitcnt vmcnt(0) before the barrier
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #define HOLO_LOAD_A(chunk_, buf_)                                                                         \
     _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
         if (tid + r * C::THREADS < C::A_UNITS)                                                            \
-            HOLO_GLDS16(ximg + a_src[r] + (chunk_) * kKC,                                                 \
+            HOLO_GLDS16(ximg + a_src[r] + (chunk_) * KC,                                                 \
                         (buf_) * C::A_BYTES + r * C::THREADS * 16 + wave_base)                           \
     }
 #define HOLO_LOAD_B(wsrc_, buf_)                                                                          \
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #define HOLO_LOAD_A(chunk_, buf_)                                                                         \
     _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
         if (tid + r * C::THREADS < C::A_UNITS)                                                            \
-            a_reg[r] = *reinterpret_cast<const float4*>(ximg + a_src[r] + (chunk_) * kKC);                \
+            a_reg[r] = *reinterpret_cast<const float4*>(ximg + a_src[r] + (chunk_) * KC);                \
     }
 #define HOLO_STORE_A(buf_)                                                                                \
     _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
     const int lpy = wm * 4 + ((li >> 1) & 1);  // + 2*mt
     int b_off[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) b_off[nt] = swz(wn * 64 + nt * 32 + li, hsel);
+    for (int nt = 0; nt < 2; ++nt) b_off[nt] = swz<KC>(wn * 64 + nt * 32 + li, hsel);
 
     // acc: the MFMA chain of the current 16-channel chunk (9 taps x 16 channels = 144 terms);
     // tot: running sum of the finished chunks.  One fp32 fmaf chain over all 9*Cin terms (up to 4608)
@@ -206,8 +218,8 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
     // [chunk][tap][N][16]) and the two LDS buffer parities are toggled, so a stage carries no div/mod or
     // 64-bit multiply.  With the per-chunk fold the first MFMA of a chunk takes C = 0 (an inline constant):
     // the accumulators are never zeroed.
-    const float* __restrict__ wsrc = wp + (size_t)n0 * kKC;
-    const size_t w_stage = (size_t)N * kKC;
+    const float* __restrict__ wsrc = wp + (size_t)n0 * KC;
+    const size_t w_stage = (size_t)N * KC;
     HOLO_LOAD_A(0, 0)
     HOLO_LOAD_B(wsrc, 0)
     HOLO_STORE_A(0)
@@ -235,10 +247,12 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int q = (lpy + 2 * mt + dy) * C::HW + lpx + dx;
-                a_off[mt] = swz(q, hsel);
+                a_off[mt] = swz<KC>(q, hsel);
             }
+            // lanes 0-31 read unit 2j, lanes 32-63 unit 2j+1 (the k = lane>>5 split of the 32x32x2 MFMA); the
+            // swizzle is an XOR on the unit index, so unit 2j+h sits at (offset of unit h) ^ (j << 5)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < KC / 8; ++j) {
                 float4 av[2], bv[2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const float4*>(abuf + (a_off[mt] ^ (j << 5)));
@@ -342,10 +356,10 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #undef HOLO_STORE_B
 #undef HOLO_STAGE_WAIT
 
-template <int WM, int WN, bool CONVT>
+template <int WM, int WN, bool CONVT, int KC>
 static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int batch, int h, int w, int cin,
                        int cout, int relu, int pool, hipStream_t stream) {
-    using C = ConvCfg<WM, WN, CONVT>;
+    using C = ConvCfg<WM, WN, CONVT, KC>;
     const int n = CONVT ? 4 * cout : cout;
     const int tiles_x = ceil_div(w, kPW), tiles_y = ceil_div(h, C::PR);
     const long blocks = (long)batch * tiles_x * tiles_y * (n / C::TN);
@@ -353,41 +367,51 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
     static bool attr_done = false;
     if (!attr_done) {
         if (C::LDS_BYTES > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<WM, WN, CONVT>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<WM, WN, CONVT, KC>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, CONVT>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, CONVT, KC>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
                        stream, x, wp, bias, y, h, w, cin, cout, n, tiles_x, tiles_y, relu, pool);
     return check_launch(CONVT ? "holo_convt2x2_f32" : "holo_conv3x3_f32");
 }
 
 // ---- weight packing --------------------------------------------------------------------------------------------
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin) {
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int kc) {
     const long total = (long)9 * cin * cout;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int k = (int)(i % kKC);
-    long r = i / kKC;
+    const int k = (int)(i % kc);
+    long r = i / kc;
     const int co = (int)(r % cout);
     r /= cout;
     const int tap = (int)(r % 9);
     const int chunk = (int)(r / 9);
-    const int ci = chunk * kKC + k;
-    out[i] = w[((long)co * cin + ci) * 9 + tap];  // OIHW, tap = ky*3+kx; packed [chunk][tap][co][16]
+    const int ci = chunk * kc + k;
+    out[i] = w[((long)co * cin + ci) * 9 + tap];  // OIHW, tap = ky*3+kx; packed [chunk][tap][co][kc]
 }
 
-__global__ void pack_convt2x2_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout) {
+__global__ void pack_convt2x2_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int kc) {
     const long total = (long)4 * cin * cout;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int k = (int)(i % kKC);
-    long r = i / kKC;
+    const int k = (int)(i % kc);
+    long r = i / kc;
     const int n = (int)(r % (4 * cout));
     const int chunk = (int)(r / (4 * cout));
     const int q = n / cout, co = n % cout;
-    const int ci = chunk * kKC + k;
+    const int ci = chunk * kc + k;
     out[i] = w[((long)ci * cout + co) * 4 + q];  // (Cin,Cout,2,2), q = dy*2+dx
+}
+
+// K-chunk per stage for a layer: the packing and the launch must agree.  32-channel stages (half the barriers,
+// 78 KB of LDS, 256 VGPRs) measured within 0.3 % of 16-channel stages on MI355X, so the leaner 16 is used;
+// HOLO_CONV_KC32=1 at build time selects 32 for the 128-wide tile (kept for experiments / other dtypes).
+#ifndef HOLO_CONV_KC32
+#define HOLO_CONV_KC32 0
+#endif
+static int conv_kc(int cin, int cout, bool convt) {
+    return (HOLO_CONV_KC32 && !convt && cout % 128 == 0 && cin % 32 == 0) ? 32 : 16;
 }
 
 }  // namespace holo
@@ -404,7 +428,7 @@ int holo_pack_conv3x3_weight_f32(const float* w_oihw, float* w_packed, int cout,
                  "holo_pack_conv3x3_weight_f32: Cin=%d must be a positive multiple of 16 (Cout=%d)", cin, cout);
     const long total = (long)9 * cin * cout;
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       w_oihw, w_packed, cout, cin);
+                       w_oihw, w_packed, cout, cin, conv_kc(cin, cout, false));
     return check_launch("holo_pack_conv3x3_weight_f32");
 }
 
@@ -415,7 +439,7 @@ int holo_pack_convt2x2_weight_f32(const float* w_iohw, float* w_packed, int cin,
                  "holo_pack_convt2x2_weight_f32: Cin=%d must be a positive multiple of 16 (Cout=%d)", cin, cout);
     const long total = (long)4 * cin * cout;
     hipLaunchKernelGGL(pack_convt2x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       w_iohw, w_packed, cin, cout);
+                       w_iohw, w_packed, cin, cout, conv_kc(cin, cout, true));
     return check_launch("holo_pack_convt2x2_weight_f32");
 }
 
@@ -431,8 +455,12 @@ int holo_conv3x3_f32(const float* x_nhwc, const float* w_packed, const float* bi
     HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
                  "holo_conv3x3_f32: one image must stay below 2^31 elements");
     hipStream_t s = as_stream(stream);
-    if (cout % 128 == 0) return launch_conv<2, 2, false>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
-    return launch_conv<4, 1, false>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+    if (cout % 128 == 0) {
+        if (conv_kc(cin, cout, false) == 32)
+            return launch_conv<2, 2, false, 32>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+        return launch_conv<2, 2, false, 16>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+    }
+    return launch_conv<4, 1, false, 16>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
 }
 
 int holo_convt2x2_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc, int batch, int h,
@@ -447,8 +475,8 @@ int holo_convt2x2_f32(const float* x_nhwc, const float* w_packed, const float* b
     // N = 4*Cout is always a multiple of 128 here (Cout % 64 == 0 -> a 128-wide tile may straddle two
     // (dy,dx) quadrants only if Cout % 128 != 0; then use the 64-wide tile)
     hipStream_t s = as_stream(stream);
-    if (cout % 128 == 0) return launch_conv<2, 2, true>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
-    return launch_conv<4, 1, true>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
+    if (cout % 128 == 0) return launch_conv<2, 2, true, 16>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
+    return launch_conv<4, 1, true, 16>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
 }
 
 }  // extern "C"

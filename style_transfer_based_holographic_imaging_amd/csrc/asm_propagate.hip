@@ -34,22 +34,9 @@ namespace holo {
 
 constexpr int kRowThreads = 256;
 
-// ---- tables: packed per-pass twiddles (forward plan, and the inverse plan where it differs) and the squared
-// signed frequencies (k/(P px))^2 -------------------------------------------------------------------------
-constexpr int kTwSlots = 4096;   // float2 entries reserved per table in the workspace (generic path: P <= 4096)
-
-template <int P>
-__global__ void asm_tables_kernel(float2* twf, float2* twi, double* f2, double ppx) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
-    fft_fill_twiddles<P, -1>(twf, tid, n);
-    if (!fft_plan_symmetric<P>()) fft_fill_twiddles<P, +1>(twi, tid, n);
-    for (int m = tid; m < P; m += n) {
-        // numpy: fx = (arange(2S)/2 - S//2)/(S*px)  ==  signed_bin/(P*px) bit for bit; then fx**2
-        const int ks = m < P / 2 ? m : m - P;
-        const double f = (double)ks / ppx;
-        f2[m] = f * f;
-    }
-}
+// workspace head: tables of the generic-size path (twiddles W_P^m and squared frequencies, P <= 4096); the
+// power-of-two kernels build their twiddles in LDS themselves and need no table
+constexpr int kTwSlots = 4096;
 
 // sin/cos for arguments of moderate size: Cody-Waite reduction by pi/2 with FMA (three-part constant),
 // minimax polynomials on [-pi/4, pi/4]; ~1 ulp.  Large arguments take the library path.
@@ -116,7 +103,7 @@ __host__ __device__ constexpr int tw_entries_inv() { return fft_tw_total<P, +1>(
 template <int P, bool PAD>
 __global__ __launch_bounds__(kRowThreads) void asm_rows_fwd_kernel(
     const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
-    float phase_scale, v2f* __restrict__ tbuf, const v2f* __restrict__ twf_g, long n_rows) {
+    float phase_scale, v2f* __restrict__ tbuf, long n_rows) {
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = FftGeom<P>::G;       // lanes per row (<= one wave)
     constexpr int SEQ = kRowThreads / G;   // rows per block
@@ -134,7 +121,7 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_fwd_kernel(
     const long row = (long)blockIdx.x * SEQ + seq;
     const bool valid = row < n_rows;
     v2f* my = buf + seq * PITCH;
-    for (int i = tid; i < TWN; i += kRowThreads) tw[i] = twf_g[i];
+    fft_fill_twiddles<P, -1>(tw, tid, kRowThreads);
 
     v2f v[E];
     {
@@ -189,9 +176,8 @@ struct ColCfg {
 
 template <int P, bool PAD>
 __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void asm_cols_kernel(
-    const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const v2f* __restrict__ twf_g,
-    const v2f* __restrict__ twi_g, const double* __restrict__ f2_g, const double* __restrict__ phase_const,
-    int n_dist, double lam2, double lamb, int ablate) {
+    const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const double* __restrict__ phase_const,
+    int n_dist, double inv_ppx, double lam2, double lamb, int ablate) {
     using C = ColCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int CW = C::CW, G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
@@ -208,9 +194,8 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
     const int fo = blockIdx.y;          // output field = field * n_dist + dist
     const int f = fo / n_dist;
     const int kx0 = blockIdx.x * CW;
-    for (int i = tid; i < tw_entries_fwd<P>(); i += THREADS) twf[i] = twf_g[i];
-    if (!SYM)
-        for (int i = tid; i < tw_entries_inv<P>(); i += THREADS) twi[i] = twi_g[i];
+    fft_fill_twiddles<P, -1>(twf, tid, THREADS);
+    if (!SYM) fft_fill_twiddles<P, +1>(twi, tid, THREADS);
     // coalesced read of S rows x CW columns, transposed into per-column sequences (compact: S entries)
     const v2f* src = tbuf + (long)f * S * P + kx0;
     for (int i = tid; i < S * CW; i += THREADS) {
@@ -235,10 +220,15 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
     // LDS region is private to its G lanes (one wave or less): wave-local ordering, no block barrier.
     fft_sync<G>();
     {
+        // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
         const double c_over_l = phase_const[fo] / lamb;
-        const double fx2 = f2_g[kx0 + col];
-        for (int m = t; m <= P / 2; m += G)
-            my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + f2_g[m], lam2, c_over_l);
+        const int kx = kx0 + col;
+        const double fx = (double)(kx < P / 2 ? kx : kx - P) * inv_ppx;
+        const double fx2 = fx * fx;
+        for (int m = t; m <= P / 2; m += G) {
+            const double fy = (double)m * inv_ppx;
+            my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
+        }
     }
     fft_sync<G>();
 #pragma unroll
@@ -268,7 +258,7 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
 template <int P, bool PAD>
 __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
     const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode,
-    long ostride0, long ostride1, const v2f* __restrict__ twi_g, long n_rows, float scale) {
+    long ostride0, long ostride1, long n_rows, float scale) {
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = FftGeom<P>::G;
     constexpr int SEQ = kRowThreads / G;
@@ -286,7 +276,7 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
     const long row = (long)blockIdx.x * SEQ + seq;
     const bool valid = row < n_rows;
     v2f* my = buf + seq * PITCH;
-    for (int i = tid; i < TWN; i += kRowThreads) tw[i] = twi_g[i];
+    fft_fill_twiddles<P, +1>(tw, tid, kRowThreads);
     v2f v[E];
     {
         const v2f* src = ubuf + (valid ? row : 0) * P;
@@ -345,7 +335,6 @@ static int launch_asm(const AsmArgs& a) {
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = FftGeom<P>::G;
     constexpr int SEQ = kRowThreads / G;
-    constexpr bool SYM = fft_plan_symmetric<P>();
     const size_t row_lds_f = (size_t)(tw_entries_fwd<P>() + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
     const size_t row_lds_i = (size_t)(tw_entries_inv<P>() + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
     const size_t col_lds = C::LDS;
@@ -362,21 +351,18 @@ static int launch_asm(const AsmArgs& a) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
         attr_done = true;
     }
-    v2f* twf = reinterpret_cast<v2f*>(a.twf);
-    v2f* twi = SYM ? twf : reinterpret_cast<v2f*>(a.twi);
-    hipLaunchKernelGGL((asm_tables_kernel<P>), dim3(ceil_div(P, 256)), dim3(256), 0, a.stream, a.twf, a.twi, a.f2, a.ppx);
     const long rows_in = (long)a.n_fields * S;
     hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kRowThreads),
                        row_lds_f, a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale,
-                       reinterpret_cast<v2f*>(a.tbuf), twf, rows_in);
+                       reinterpret_cast<v2f*>(a.tbuf), rows_in);
     hipLaunchKernelGGL((asm_cols_kernel<P, PAD>), dim3(P / C::CW, a.n_fields * a.n_dist), dim3(C::THREADS), col_lds,
-                       a.stream, reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), twf, twi, a.f2,
-                       a.phase_const, a.n_dist, a.lam2, a.lamb, a.ablate);
+                       a.stream, reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const,
+                       a.n_dist, 1.0 / a.ppx, a.lam2, a.lamb, a.ablate);
     const long rows_out = rows_in * a.n_dist;
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
     hipLaunchKernelGGL((asm_rows_inv_kernel<P, PAD>), dim3((unsigned)((rows_out + SEQ - 1) / SEQ)), dim3(kRowThreads),
                        row_lds_i, a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0,
-                       a.os1, twi, rows_out, scale);
+                       a.os1, rows_out, scale);
     return check_launch("holo_asm_propagate");
 }
 

@@ -104,17 +104,20 @@ __host__ __device__ constexpr int fft_tw_offset(int i) {
 template <int P, int DIR>
 __host__ __device__ constexpr int fft_tw_total() { return fft_tw_offset<P, DIR>(FftPlan<P>::n); }
 
-// fills `tw` (fft_tw_total<P,DIR>() entries); call with any number of threads, tid/nthreads striding
+// Fills the packed table of direction DIR (fft_tw_total<P,DIR>() entries) cooperatively, e.g. straight into
+// LDS at kernel start.  The angles are dyadic rationals (-2*r*k/(Ns*R) half-turns, exact in fp32), so
+// sincospif reduces them exactly and the entries are good to ~1 ulp; a few dozen instructions per thread,
+// which removes a table kernel and a launch boundary from every propagation call.
 template <int P, int DIR>
-__device__ void fft_fill_twiddles(float2* tw, int tid, int nthreads) {
+__device__ __forceinline__ void fft_fill_twiddles(v2f* tw, int tid, int nthreads) {
 #pragma unroll
     for (int i = 1; i < FftPlan<P>::n; ++i) {
         const int R = fft_radix<P, DIR>(i), NS = fft_ns<P, DIR>(i), off = fft_tw_offset<P, DIR>(i);
         for (int e = tid; e < NS * (R - 1); e += nthreads) {
             const int k = e / (R - 1), r = e % (R - 1) + 1;
-            double s, c;
-            sincospi(-2.0 * (double)(r * k) / (double)(NS * R), &s, &c);
-            tw[off + e] = make_float2((float)c, (float)s);
+            float sn, cs;
+            sincospif(-2.0f * (float)(r * k) / (float)(NS * R), &sn, &cs);
+            tw[off + e] = v2f{cs, sn};
         }
     }
 }

@@ -31,6 +31,7 @@ if REPO not in sys.path:
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparse headline)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 FLOP_PER_PIXEL = 1136262       # conv stack per input pixel (+5.24 MFLOP distance head)
 
@@ -105,6 +106,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=4, help="holograms in the CPU baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="conv stack arithmetic: f32 = exact fp32 MFMA (BASELINE configs[1], the parity path); "
+                         "bf16 = bf16 MFMA with fp32 accumulation (configs[2]); the propagator is fp32 either way")
     args = ap.parse_args()
 
     from style_transfer_based_holographic_imaging_amd import ops, shard, synth
@@ -120,6 +124,8 @@ def main():
     from utils.functions import field_retrieval
 
     network, sds = build_network(dev)
+    if args.dtype == "bf16":
+        network.set_compute_dtype(torch.bfloat16)
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     from holo_oracle import HoloParams
     model_forward = Holo_Generator(HoloParams())
@@ -175,23 +181,25 @@ def main():
             "metric": "holograms/sec (256x256 complex field retrieval)" if s == 256 else f"holograms/sec ({s}x{s} complex field retrieval)",
             "value": round(total / elapsed, 2), "unit": "holograms/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: batch {b}/GPU synthetic {s}x{s} holograms, fp32, VGG-AdaIN-decoder + "
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: batch {b}/GPU synthetic {s}x{s} holograms, "
+                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 convs / fp32 FFT'}, VGG-AdaIN-decoder + "
                                    f"distance head + angular-spectrum back-propagation (P={2 * s}), seeded He-normal weights",
                        "batch_per_gpu": b, "size": s, "parallelism": f"batch-sharded x{world}, one RCCL gather per step"},
         }
         if timer is not None:
             summ = timer.summary()
-            conv = [summ[k] for k in ("holo_conv3x3_f32", "holo_convt2x2_f32") if k in summ]
+            conv = [summ[k] for k in (f"holo_conv3x3_{args.dtype}", f"holo_convt2x2_{args.dtype}") if k in summ]
+            peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
             if conv:
                 fl = sum(r["flops"] for r in conv)
                 ms = sum(r["ms"] for r in conv)
                 calls = sum(r["calls"] for r in conv)
                 ach = fl / (ms * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(b, s),
+                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4), "traffic": pmc_traffic(b, s) if args.dtype == "f32" else None,
                                    "algorithmic_bytes_per_launch": round(sum(r["bytes"] for r in conv) / calls),
-                                   "kernel": "conv_mfma_f32_kernel (3x3 + transposed, all layers)",
+                                   "kernel": f"conv_mfma_kernel<{args.dtype}> (3x3 + transposed, all layers)",
                                    "launches_per_step": calls // args.steps, "avg_launch_ms": round(ms / calls, 4),
                                    "gflop_per_launch": round(fl / calls / 1e9, 3)}
             if "holo_asm_propagate" in summ:

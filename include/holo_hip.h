@@ -133,6 +133,29 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * bf16 variants (BASELINE config 3: "bf16 convs / fp32 FFT").  Same layouts and semantics as the _f32 entry
+ * points; activations and packed weights are bf16 (uint16_t storage), bias, statistics, accumulation
+ * (v_mfma_f32_32x32x16_bf16) and the last layer's amplitude/phase planes stay fp32.  Cin % 32 == 0.
+ * ---------------------------------------------------------------------------------------- */
+int holo_pack_conv3x3_weight_bf16(const float* w_oihw, uint16_t* w_packed, int cout, int cin, void* stream);
+int holo_pack_convt2x2_weight_bf16(const float* w_iohw, uint16_t* w_packed, int cin, int cout, void* stream);
+int holo_conv_first_bf16(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                         uint16_t* y_nhwc, int batch, int h, int w, void* stream);
+int holo_conv3x3_bf16(const uint16_t* x_nhwc, const uint16_t* w_packed, const float* bias, uint16_t* y_nhwc,
+                      int batch, int h, int w, int cin, int cout, int relu, int pool, void* stream);
+int holo_convt2x2_bf16(const uint16_t* x_nhwc, const uint16_t* w_packed, const float* bias, uint16_t* y_nhwc,
+                       int batch, int h, int w, int cin, int cout, int relu, void* stream);
+int holo_conv_last_bf16(const uint16_t* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw,
+                        int batch, int h, int w, void* stream);
+int holo_channel_mean_std_bf16(const uint16_t* x_nhwc, float* mean, float* std, int batch, int hw, int c,
+                               float eps, void* stream);
+int holo_adain_apply_bf16(const uint16_t* x_nhwc, const float* mean, const float* std, const float* style_mean,
+                          const float* style_std, long style_batch_stride, float alpha, uint16_t* y_nhwc,
+                          int batch, int hw, int c, void* stream);
+int holo_cast_f32_to_bf16(const float* x, uint16_t* y, long n, void* stream);
+int holo_cast_bf16_to_f32(const uint16_t* x, float* y, long n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Layout helpers
  * ---------------------------------------------------------------------------------------- */
 int holo_nhwc_to_nchw_f32(const float* x, float* y, int batch, int hw, int c, void* stream);

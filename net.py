@@ -82,6 +82,14 @@ class Net(nn.Module):
             for param in getattr(self, f"enc_{k + 1}").parameters():
                 param.requires_grad = False
 
+    def set_compute_dtype(self, dtype):
+        """Additive: torch.float32 (default, exact fp32 MFMA) or torch.bfloat16 for the conv stack
+        (BASELINE config 3).  Inputs, amplitude/phase outputs, statistics and the distance head stay fp32."""
+        for k in range(self.n_layer):
+            getattr(self, f"enc_{k + 1}").set_compute_dtype(dtype)
+        self.decoder.set_compute_dtype(dtype)
+        return self
+
     def encode_with_intermediate(self, input):
         results = [input]
         for i in range(self.n_layer):

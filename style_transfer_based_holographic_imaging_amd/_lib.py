@@ -43,6 +43,16 @@ SIGNATURES = {
     "holo_linear1_sigmoid_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "holo_asm_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "holo_asm_propagate": (_i, [_p, _p, _i, _l, _l, _p, _p, _i, _l, _l, _p, _i, _i, _i, _i, _d, _d, _f, _p, _z, _p]),
+    "holo_pack_conv3x3_weight_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "holo_pack_convt2x2_weight_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "holo_conv_first_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_conv3x3_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "holo_convt2x2_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "holo_conv_last_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_channel_mean_std_bf16": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
+    "holo_adain_apply_bf16": (_i, [_p, _p, _p, _p, _p, _l, _f, _p, _i, _i, _i, _p]),
+    "holo_cast_f32_to_bf16": (_i, [_p, _p, _l, _p]),
+    "holo_cast_bf16_to_f32": (_i, [_p, _p, _l, _p]),
     "holo_nhwc_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "holo_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p]),
 }

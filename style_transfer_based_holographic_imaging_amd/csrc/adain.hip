@@ -4,10 +4,34 @@
 
 namespace holo {
 
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive channels as fp32, from fp32 or bf16 storage
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const float4*>(p);
+    } else {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float4 o) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(p) = o;
+    } else {
+        const bf16x4 v = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+        *reinterpret_cast<bf16x4*>(p) = v;
+    }
+}
+
 // grid (C/64, B); 16 lanes x float4 cover 64 channels of one pixel (256 contiguous bytes),
 // 16 pixel groups per block stride over HW; sums are kept in float64 (the CPU reference's var/mean
 // accumulate in double as well), reduced through LDS.
-__global__ __launch_bounds__(256) void channel_mean_std_kernel(const float* __restrict__ x, float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void channel_mean_std_kernel(const T* __restrict__ x, float* __restrict__ mean,
                                                                float* __restrict__ stdv, int hw, int c, float eps) {
     __shared__ double s_sum[16][64];
     __shared__ double s_sq[16][64];
@@ -15,10 +39,10 @@ __global__ __launch_bounds__(256) void channel_mean_std_kernel(const float* __re
     const int cq = tid & 15, pg = tid >> 4;
     const int c0 = blockIdx.x * 64;
     const int b = blockIdx.y;
-    const float* __restrict__ xb = x + (size_t)b * hw * c + c0 + 4 * cq;
+    const T* __restrict__ xb = x + (size_t)b * hw * c + c0 + 4 * cq;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     for (int p = pg; p < hw; p += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * c);
+        const float4 v = load4<T>(xb + (size_t)p * c);
         s[0] += v.x; q[0] += (double)v.x * v.x;
         s[1] += v.y; q[1] += (double)v.y * v.y;
         s[2] += v.z; q[2] += (double)v.z * v.z;
@@ -46,18 +70,19 @@ __global__ __launch_bounds__(256) void channel_mean_std_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void adain_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void adain_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ stdv,
                                                           const float* __restrict__ smean,
                                                           const float* __restrict__ sstd, long sstride, float alpha,
-                                                          float one_minus_alpha, float* __restrict__ y, long total4,
+                                                          float one_minus_alpha, T* __restrict__ y, long total4,
                                                           int hw, int c) {
 #pragma clang fp contract(off)
     const int c4n = c >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         const int c4 = (int)(i % c4n);
         const long b = i / ((long)c4n * hw);
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 v = load4<T>(x + 4 * i);
         const float4 mu = reinterpret_cast<const float4*>(mean + b * c)[c4];
         const float4 sd = reinterpret_cast<const float4*>(stdv + b * c)[c4];
         const float4 sm = reinterpret_cast<const float4*>(smean + b * sstride)[c4];
@@ -68,43 +93,59 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const float* __restric
         o.y = alpha * (((v.y - mu.y) / sd.y) * ss.y + sm.y) + one_minus_alpha * v.y;
         o.z = alpha * (((v.z - mu.z) / sd.z) * ss.z + sm.z) + one_minus_alpha * v.z;
         o.w = alpha * (((v.w - mu.w) / sd.w) * ss.w + sm.w) + one_minus_alpha * v.w;
-        reinterpret_cast<float4*>(y)[i] = o;
+        store4<T>(y + 4 * i, o);
     }
+}
+
+template <typename T>
+static int mean_std_entry(const T* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps, void* stream) {
+    HOLO_REQUIRE(x_nhwc && mean && std, HOLO_ERR_ARG, "holo_channel_mean_std: null pointer");
+    HOLO_REQUIRE(batch > 0 && batch <= 65535 && hw >= 1 && c > 0 && c % 64 == 0, HOLO_ERR_ARG,
+                 "holo_channel_mean_std: batch=%d hw=%d c=%d (c must be a multiple of 64, batch <= 65535)", batch, hw, c);
+    hipLaunchKernelGGL((channel_mean_std_kernel<T>), dim3(c / 64, batch), dim3(256), 0, as_stream(stream), x_nhwc, mean, std,
+                       hw, c, eps);
+    return check_launch("holo_channel_mean_std");
+}
+
+template <typename T>
+static int adain_entry(const T* x_nhwc, const float* mean, const float* std, const float* style_mean,
+                       const float* style_std, long style_batch_stride, float alpha, T* y_nhwc, int batch, int hw, int c,
+                       void* stream) {
+    HOLO_REQUIRE(x_nhwc && mean && std && style_mean && style_std && y_nhwc, HOLO_ERR_ARG, "holo_adain_apply: null pointer");
+    HOLO_REQUIRE(batch > 0 && hw >= 1 && c > 0 && c % 4 == 0 && style_batch_stride % 4 == 0, HOLO_ERR_ARG,
+                 "holo_adain_apply: batch=%d hw=%d c=%d style_stride=%ld", batch, hw, c, style_batch_stride);
+    HOLO_REQUIRE(alpha >= 0.0f && alpha <= 1.0f, HOLO_ERR_ARG, "holo_adain_apply: alpha=%f outside [0,1]", alpha);
+    const long total4 = (long)batch * hw * (c / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    // net.py:246: `(1 - alpha)` is evaluated in Python double precision, then meets the fp32 tensor
+    const float one_minus = (float)(1.0 - (double)alpha);
+    hipLaunchKernelGGL((adain_apply_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x_nhwc, mean, std,
+                       style_mean, style_std, style_batch_stride, alpha, one_minus, y_nhwc, total4, hw, c);
+    return check_launch("holo_adain_apply");
 }
 
 }  // namespace holo
 
 extern "C" {
 
-int holo_channel_mean_std_f32(const float* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps,
-                              void* stream) {
-    using namespace holo;
-    HOLO_REQUIRE(x_nhwc && mean && std, HOLO_ERR_ARG, "holo_channel_mean_std_f32: null pointer");
-    HOLO_REQUIRE(batch > 0 && batch <= 65535 && hw >= 1 && c > 0 && c % 64 == 0, HOLO_ERR_ARG,
-                 "holo_channel_mean_std_f32: batch=%d hw=%d c=%d (c must be a multiple of 64, batch <= 65535)", batch,
-                 hw, c);
-    hipLaunchKernelGGL(channel_mean_std_kernel, dim3(c / 64, batch), dim3(256), 0, as_stream(stream), x_nhwc, mean, std,
-                       hw, c, eps);
-    return check_launch("holo_channel_mean_std_f32");
+int holo_channel_mean_std_f32(const float* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps, void* stream) {
+    return holo::mean_std_entry<float>(x_nhwc, mean, std, batch, hw, c, eps, stream);
 }
-
+int holo_channel_mean_std_bf16(const uint16_t* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps, void* stream) {
+    return holo::mean_std_entry<holo::bf16_t>(reinterpret_cast<const holo::bf16_t*>(x_nhwc), mean, std, batch, hw, c, eps, stream);
+}
 int holo_adain_apply_f32(const float* x_nhwc, const float* mean, const float* std, const float* style_mean,
                          const float* style_std, long style_batch_stride, float alpha, float* y_nhwc, int batch, int hw,
                          int c, void* stream) {
-    using namespace holo;
-    HOLO_REQUIRE(x_nhwc && mean && std && style_mean && style_std && y_nhwc, HOLO_ERR_ARG,
-                 "holo_adain_apply_f32: null pointer");
-    HOLO_REQUIRE(batch > 0 && hw >= 1 && c > 0 && c % 4 == 0 && style_batch_stride % 4 == 0, HOLO_ERR_ARG,
-                 "holo_adain_apply_f32: batch=%d hw=%d c=%d style_stride=%ld", batch, hw, c, style_batch_stride);
-    HOLO_REQUIRE(alpha >= 0.0f && alpha <= 1.0f, HOLO_ERR_ARG, "holo_adain_apply_f32: alpha=%f outside [0,1]", alpha);
-    const long total4 = (long)batch * hw * (c / 4);
-    long blocks = (total4 + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    // net.py:246: `(1 - alpha)` is evaluated in Python double precision, then meets the fp32 tensor
-    const float one_minus = (float)(1.0 - (double)alpha);
-    hipLaunchKernelGGL(adain_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x_nhwc, mean, std,
-                       style_mean, style_std, style_batch_stride, alpha, one_minus, y_nhwc, total4, hw, c);
-    return check_launch("holo_adain_apply_f32");
+    return holo::adain_entry<float>(x_nhwc, mean, std, style_mean, style_std, style_batch_stride, alpha, y_nhwc, batch, hw, c, stream);
+}
+int holo_adain_apply_bf16(const uint16_t* x_nhwc, const float* mean, const float* std, const float* style_mean,
+                          const float* style_std, long style_batch_stride, float alpha, uint16_t* y_nhwc, int batch, int hw,
+                          int c, void* stream) {
+    using holo::bf16_t;
+    return holo::adain_entry<bf16_t>(reinterpret_cast<const bf16_t*>(x_nhwc), mean, std, style_mean, style_std,
+                                     style_batch_stride, alpha, reinterpret_cast<bf16_t*>(y_nhwc), batch, hw, c, stream);
 }
 
 }  // extern "C"

@@ -40,16 +40,24 @@
 namespace holo {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kKC = 16;  // smallest K chunk (channels); weights/activations need Cin % 16 == 0
 constexpr int kPW = 16;  // patch width in pixels
 
 // KC = channels per stage: 16 (one 64-B LDS row per pixel / output channel) or 32 (128-B rows, twice the MFMAs
 // between two barriers; used where the deeper buffers still leave two blocks per CU)
-template <int WM, int WN, bool CONVT, int KC>
+// T = float (exact fp32 MFMA, v_mfma_f32_32x32x2_f32) or bf16_t (v_mfma_f32_32x32x16_bf16, fp32 accumulate; BASELINE
+// config 3 "bf16 convs").  With 64-byte rows (16 fp32 / 32 bf16 channels) the staging plan, the swizzle and the
+// fragment reads are byte-for-byte the same for both: a lane's 16-byte read is 4 fp32 k-steps or one bf16 MFMA.
+template <int WM, int WN, bool CONVT, int KC, typename T>
 struct ConvCfg {
-    static constexpr int UPR = KC / 4;   // 16-byte units per LDS row
-    static constexpr int ROWB = KC * 4;  // bytes per LDS row
+    static constexpr int ES = (int)sizeof(T);
+    static constexpr int EPU = 16 / ES;        // elements per 16-byte unit
+    static constexpr int UPR = KC * ES / 16;   // 16-byte units per LDS row
+    static constexpr int ROWB = KC * ES;       // bytes per LDS row
+    static_assert(ROWB == 64 || ROWB == 128, "LDS rows are 64 or 128 bytes");
     static constexpr int PR = WM * 4;  // patch rows
     static constexpr int TN = WN * 64;
     static constexpr int HALO = CONVT ? 0 : 1;
@@ -70,18 +78,19 @@ struct ConvCfg {
 // byte offset of 16-byte unit `unit` of LDS row `row`: the unit index is XOR-swizzled with row bits so that the
 // ds_read_b128 of 16 consecutive rows at one unit covers all 64 banks (64-B rows: 4 rows per 256-B bank row,
 // swizzle by row>>2; 128-B rows: 2 rows per bank row, swizzle by row>>1)
-template <int KC>
+template <int ROWB>
 __device__ __forceinline__ int swz_unit(int row, int unit) {
-    return KC == 16 ? (unit ^ ((row >> 2) & 3)) : (unit ^ ((row >> 1) & 7));
+    return ROWB == 64 ? (unit ^ ((row >> 2) & 3)) : (unit ^ ((row >> 1) & 7));
 }
-template <int KC>
-__device__ __forceinline__ int swz(int row, int unit) { return row * (KC * 4) + (swz_unit<KC>(row, unit) << 4); }
+template <int ROWB>
+__device__ __forceinline__ int swz(int row, int unit) { return row * ROWB + (swz_unit<ROWB>(row, unit) << 4); }
 
-template <int WM, int WN, bool CONVT, int KC>
-__global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f32_kernel(
-    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ y, int H, int W, int Cin, int Cout, int N, int tiles_x, int tiles_y, int relu, int pool) {
-    using C = ConvCfg<WM, WN, CONVT, KC>;
+template <int WM, int WN, bool CONVT, int KC, typename T>
+__global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_kernel(
+    const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
+    T* __restrict__ y, int H, int W, int Cin, int Cout, int N, int tiles_x, int tiles_y, int relu, int pool) {
+    using C = ConvCfg<WM, WN, CONVT, KC, T>;
+    constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_a = smem;                   // [2][A_BYTES]
     unsigned char* lds_b = smem + 2 * C::A_BYTES;  // [2][B_BYTES]
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
     const int img = bid / tiles_y;
     const int y0 = ty * C::PR, x0 = tx * kPW;
     const int n0 = nb * C::TN;
-    const float* __restrict__ ximg = x + (size_t)img * H * W * Cin;
+    const T* __restrict__ ximg = x + (size_t)img * H * W * Cin;
     const int nchunks = Cin / KC;
 
     // ---- staging plans (fixed per block) -------------------------------------------------------
@@ -108,18 +117,18 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #pragma unroll
     for (int r = 0; r < C::A_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
-        const int q = u / C::UPR, c = swz_unit<KC>(q, u % C::UPR);
+        const int q = u / C::UPR, c = swz_unit<C::ROWB>(q, u % C::UPR);
         const int hy = q / C::HW, hx = q % C::HW;
         const int ry = reflect1(y0 - C::HALO + hy, H);
         const int rx = reflect1(x0 - C::HALO + hx, W);
-        a_src[r] = (ry * W + rx) * Cin + 4 * c;
+        a_src[r] = (ry * W + rx) * Cin + C::EPU * c;
     }
     int b_src[C::B_ROUNDS];
 #pragma unroll
     for (int r = 0; r < C::B_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
-        const int co = u / C::UPR, c = swz_unit<KC>(co, u % C::UPR);
-        b_src[r] = co * KC + 4 * c;
+        const int co = u / C::UPR, c = swz_unit<C::ROWB>(co, u % C::UPR);
+        b_src[r] = co * KC + C::EPU * c;
     }
 #if HOLO_CONV_GLDS
     // global_load_lds_dwordx4: no staging VGPRs, no ds_write; completion = s_waitcnt vmcnt(0) before the barrier
@@ -194,13 +203,13 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
     const int lpy = wm * 4 + ((li >> 1) & 1);  // + 2*mt
     int b_off[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) b_off[nt] = swz<KC>(wn * 64 + nt * 32 + li, hsel);
+    for (int nt = 0; nt < 2; ++nt) b_off[nt] = swz<C::ROWB>(wn * 64 + nt * 32 + li, hsel);
 
     // acc: the MFMA chain of the current 16-channel chunk (9 taps x 16 channels = 144 terms);
     // tot: running sum of the finished chunks.  One fp32 fmaf chain over all 9*Cin terms (up to 4608)
     // was measured ~8x noisier against float64 than the CPU reference's blocked sums; folding per chunk
     // shortens every chain to 144 + Cin/16 terms.  (The transposed conv has K = Cin <= 256: no fold.)
-    constexpr bool FOLD = !CONVT;
+    constexpr bool FOLD = !CONVT && F32;   // bf16 inputs dominate the error there: plain fp32 accumulation
     floatx16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
     // [chunk][tap][N][16]) and the two LDS buffer parities are toggled, so a stage carries no div/mod or
     // 64-bit multiply.  With the per-chunk fold the first MFMA of a chunk takes C = 0 (an inline constant):
     // the accumulators are never zeroed.
-    const float* __restrict__ wsrc = wp + (size_t)n0 * KC;
+    const T* __restrict__ wsrc = wp + (size_t)n0 * KC;
     const size_t w_stage = (size_t)N * KC;
     HOLO_LOAD_A(0, 0)
     HOLO_LOAD_B(wsrc, 0)
@@ -247,33 +256,44 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int q = (lpy + 2 * mt + dy) * C::HW + lpx + dx;
-                a_off[mt] = swz<KC>(q, hsel);
+                a_off[mt] = swz<C::ROWB>(q, hsel);
             }
             // lanes 0-31 read unit 2j, lanes 32-63 unit 2j+1 (the k = lane>>5 split of the 32x32x2 MFMA); the
             // swizzle is an XOR on the unit index, so unit 2j+h sits at (offset of unit h) ^ (j << 5)
 #pragma unroll
-            for (int j = 0; j < KC / 8; ++j) {
+            for (int j = 0; j < C::UPR / 2; ++j) {
                 float4 av[2], bv[2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const float4*>(abuf + (a_off[mt] ^ (j << 5)));
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bbuf + (b_off[nt] ^ (j << 5)));
+                if constexpr (F32) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const float a = k == 0 ? av[mt].x : (k == 1 ? av[mt].y : (k == 2 ? av[mt].z : av[mt].w));
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const float a = k == 0 ? av[mt].x : (k == 1 ? av[mt].y : (k == 2 ? av[mt].z : av[mt].w));
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const float b = k == 0 ? bv[nt].x : (k == 1 ? bv[nt].y : (k == 2 ? bv[nt].z : bv[nt].w));
-                            if (FOLD && tap == 0 && j == 0 && k == 0) {
-                                const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, zero, 0, 0, 0);
-                            } else {
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+                            for (int nt = 0; nt < 2; ++nt) {
+                                const float b = k == 0 ? bv[nt].x : (k == 1 ? bv[nt].y : (k == 2 ? bv[nt].z : bv[nt].w));
+                                if (FOLD && tap == 0 && j == 0 && k == 0) {
+                                    const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, zero, 0, 0, 0);
+                                } else {
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
+                                }
                             }
                         }
                     }
+                } else {
+                    // lane (r = lane&31, h = lane>>5) holds A[r][k = 8h + e], B[k = 8h + e][r]: the 8 bf16 of unit 2j+h
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mt]),
+                                                                                  __builtin_bit_cast(bf16x8, bv[nt]),
+                                                                                  acc[mt][nt], 0, 0, 0);
                 }
             }
             if (FOLD && tap == kLast) {
@@ -309,28 +329,28 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
                 // n = q*Cout + co with q = dy*2+dx: output pixel (2Y+dy, 2X+dx)
                 const int qd = n / Cout;
                 const int ody = qd >> 1, odx = qd & 1;
-                float* __restrict__ yimg = y + (size_t)img * (2 * H) * (2 * W) * Cout;
+                T* __restrict__ yimg = y + (size_t)img * (2 * H) * (2 * W) * Cout;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
                     const int X = x0 + ((m & 1) | ((m >> 2) << 1));
                     const int Y = y0 + wm * 4 + mt * 2 + ((m >> 1) & 1);
-                    if (X < W && Y < H) yimg[((size_t)(2 * Y + ody) * (2 * W) + (2 * X + odx)) * Cout + co] = v[r];
+                    if (X < W && Y < H) yimg[((size_t)(2 * Y + ody) * (2 * W) + (2 * X + odx)) * Cout + co] = (T)v[r];
                 }
             } else if (!pool) {
-                float* __restrict__ yimg = y + (size_t)img * H * W * Cout;
+                T* __restrict__ yimg = y + (size_t)img * H * W * Cout;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
                     const int X = x0 + ((m & 1) | ((m >> 2) << 1));
                     const int Y = y0 + wm * 4 + mt * 2 + ((m >> 1) & 1);
-                    if (X < W && Y < H) yimg[((size_t)Y * W + X) * Cout + co] = v[r];
+                    if (X < W && Y < H) yimg[((size_t)Y * W + X) * Cout + co] = (T)v[r];
                 }
             } else {
                 // MaxPool2d(2,2,ceil_mode=True): window = regs 4g..4g+3 (x bit0 = reg bit0, y bit0 = reg bit1);
                 // window members beyond the image edge are left out (post-ReLU values are >= 0)
                 const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
-                float* __restrict__ yimg = y + (size_t)img * Ho * Wo * Cout;
+                T* __restrict__ yimg = y + (size_t)img * Ho * Wo * Cout;
                 const int Y = y0 + wm * 4 + mt * 2;  // even
                 const int PY = Y >> 1;
 #pragma unroll
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
                         mx = fmaxf(mx, v[4 * g + 2]);
                         if (X + 1 < W) mx = fmaxf(mx, v[4 * g + 3]);
                     }
-                    if (X < W && Y < H) yimg[((size_t)PY * Wo + PX) * Cout + co] = mx;
+                    if (X < W && Y < H) yimg[((size_t)PY * Wo + PX) * Cout + co] = (T)mx;
                 }
             }
         }
@@ -356,10 +376,10 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_f3
 #undef HOLO_STORE_B
 #undef HOLO_STAGE_WAIT
 
-template <int WM, int WN, bool CONVT, int KC>
-static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int batch, int h, int w, int cin,
+template <int WM, int WN, bool CONVT, int KC, typename T>
+static int launch_conv(const T* x, const T* wp, const float* bias, T* y, int batch, int h, int w, int cin,
                        int cout, int relu, int pool, hipStream_t stream) {
-    using C = ConvCfg<WM, WN, CONVT, KC>;
+    using C = ConvCfg<WM, WN, CONVT, KC, T>;
     const int n = CONVT ? 4 * cout : cout;
     const int tiles_x = ceil_div(w, kPW), tiles_y = ceil_div(h, C::PR);
     const long blocks = (long)batch * tiles_x * tiles_y * (n / C::TN);
@@ -367,17 +387,18 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
     static bool attr_done = false;
     if (!attr_done) {
         if (C::LDS_BYTES > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f32_kernel<WM, WN, CONVT, KC>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, CONVT, KC, T>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<WM, WN, CONVT, KC>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, CONVT, KC, T>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
                        stream, x, wp, bias, y, h, w, cin, cout, n, tiles_x, tiles_y, relu, pool);
-    return check_launch(CONVT ? "holo_convt2x2_f32" : "holo_conv3x3_f32");
+    return check_launch(CONVT ? "holo_convt2x2" : "holo_conv3x3");
 }
 
 // ---- weight packing --------------------------------------------------------------------------------------------
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int kc) {
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int kc) {
     const long total = (long)9 * cin * cout;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -388,10 +409,11 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
     const int tap = (int)(r % 9);
     const int chunk = (int)(r / 9);
     const int ci = chunk * kc + k;
-    out[i] = w[((long)co * cin + ci) * 9 + tap];  // OIHW, tap = ky*3+kx; packed [chunk][tap][co][kc]
+    out[i] = (T)w[((long)co * cin + ci) * 9 + tap];  // OIHW, tap = ky*3+kx; packed [chunk][tap][co][kc]
 }
 
-__global__ void pack_convt2x2_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout, int kc) {
+template <typename T>
+__global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict__ out, int cin, int cout, int kc) {
     const long total = (long)4 * cin * cout;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -401,17 +423,82 @@ __global__ void pack_convt2x2_kernel(const float* __restrict__ w, float* __restr
     const int chunk = (int)(r / (4 * cout));
     const int q = n / cout, co = n % cout;
     const int ci = chunk * kc + k;
-    out[i] = w[((long)ci * cout + co) * 4 + q];  // (Cin,Cout,2,2), q = dy*2+dx
+    out[i] = (T)w[((long)ci * cout + co) * 4 + q];  // (Cin,Cout,2,2), q = dy*2+dx
 }
 
-// K-chunk per stage for a layer: the packing and the launch must agree.  32-channel stages (half the barriers,
-// 78 KB of LDS, 256 VGPRs) measured within 0.3 % of 16-channel stages on MI355X, so the leaner 16 is used;
-// HOLO_CONV_KC32=1 at build time selects 32 for the 128-wide tile (kept for experiments / other dtypes).
+// K-chunk per stage for a layer: the packing and the launch must agree.  fp32: 32-channel stages (half the
+// barriers, 78 KB of LDS, 256 VGPRs) measured within 0.3 % of 16-channel stages on MI355X, so the leaner 16 is
+// used (HOLO_CONV_KC32=1 at build time selects 32 for the 128-wide tile).  bf16: 32 channels = the same 64-byte rows.
 #ifndef HOLO_CONV_KC32
 #define HOLO_CONV_KC32 0
 #endif
+template <typename T>
 static int conv_kc(int cin, int cout, bool convt) {
+    if (sizeof(T) == 2) return 32;
     return (HOLO_CONV_KC32 && !convt && cout % 128 == 0 && cin % 32 == 0) ? 32 : 16;
+}
+template <typename T> constexpr int min_cin() { return sizeof(T) == 2 ? 32 : 16; }
+template <typename T> constexpr const char* dtype_name() { return sizeof(T) == 2 ? "bf16" : "f32"; }
+
+template <typename T>
+static int pack3x3_entry(const float* w_oihw, T* w_packed, int cout, int cin, void* stream) {
+    HOLO_REQUIRE(w_oihw && w_packed, HOLO_ERR_ARG, "holo_pack_conv3x3_weight_%s: null pointer", dtype_name<T>());
+    HOLO_REQUIRE(cin > 0 && cout > 0 && cin % min_cin<T>() == 0, HOLO_ERR_ARG,
+                 "holo_pack_conv3x3_weight_%s: Cin=%d must be a positive multiple of %d (Cout=%d)", dtype_name<T>(), cin,
+                 min_cin<T>(), cout);
+    const long total = (long)9 * cin * cout;
+    hipLaunchKernelGGL((pack_conv3x3_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       w_oihw, w_packed, cout, cin, conv_kc<T>(cin, cout, false));
+    return check_launch("holo_pack_conv3x3_weight");
+}
+
+template <typename T>
+static int packt2x2_entry(const float* w_iohw, T* w_packed, int cin, int cout, void* stream) {
+    HOLO_REQUIRE(w_iohw && w_packed, HOLO_ERR_ARG, "holo_pack_convt2x2_weight_%s: null pointer", dtype_name<T>());
+    HOLO_REQUIRE(cin > 0 && cout > 0 && cin % min_cin<T>() == 0, HOLO_ERR_ARG,
+                 "holo_pack_convt2x2_weight_%s: Cin=%d must be a positive multiple of %d (Cout=%d)", dtype_name<T>(), cin,
+                 min_cin<T>(), cout);
+    const long total = (long)4 * cin * cout;
+    hipLaunchKernelGGL((pack_convt2x2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       w_iohw, w_packed, cin, cout, conv_kc<T>(cin, cout, true));
+    return check_launch("holo_pack_convt2x2_weight");
+}
+
+template <typename T>
+static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, T* y_nhwc, int batch, int h, int w,
+                         int cin, int cout, int relu, int pool, void* stream) {
+    HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc, HOLO_ERR_ARG, "holo_conv3x3_%s: null pointer", dtype_name<T>());
+    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG,
+                 "holo_conv3x3_%s: batch=%d h=%d w=%d (reflection padding needs h,w >= 2)", dtype_name<T>(), batch, h, w);
+    HOLO_REQUIRE(cin > 0 && cin % min_cin<T>() == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_%s: Cin=%d must be a multiple of %d and Cout=%d of 64", dtype_name<T>(), cin, min_cin<T>(), cout);
+    HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_%s: fused pooling requires relu", dtype_name<T>());
+    HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_%s: one image must stay below 2^31 elements", dtype_name<T>());
+    hipStream_t s = as_stream(stream);
+    constexpr int KCD = sizeof(T) == 2 ? 32 : 16;   // default K chunk of the dtype
+    if (cout % 128 == 0) {
+        if (sizeof(T) == 4 && conv_kc<T>(cin, cout, false) == 32)
+            return launch_conv<2, 2, false, 32, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+        return launch_conv<2, 2, false, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+    }
+    return launch_conv<4, 1, false, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+}
+
+template <typename T>
+static int convt2x2_entry(const T* x_nhwc, const T* w_packed, const float* bias, T* y_nhwc, int batch, int h, int w,
+                          int cin, int cout, int relu, void* stream) {
+    HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc, HOLO_ERR_ARG, "holo_convt2x2_%s: null pointer", dtype_name<T>());
+    HOLO_REQUIRE(batch > 0 && h >= 1 && w >= 1, HOLO_ERR_ARG, "holo_convt2x2_%s: batch=%d h=%d w=%d", dtype_name<T>(), batch, h, w);
+    HOLO_REQUIRE(cin > 0 && cin % min_cin<T>() == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_convt2x2_%s: Cin=%d must be a multiple of %d and Cout=%d of 64", dtype_name<T>(), cin, min_cin<T>(), cout);
+    HOLO_REQUIRE((long)h * w * 4 * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
+                 "holo_convt2x2_%s: one image must stay below 2^31 elements", dtype_name<T>());
+    // a 128-wide N tile would straddle two (dy,dx) quadrants when Cout % 128 != 0: use the 64-wide tile then
+    hipStream_t s = as_stream(stream);
+    constexpr int KCD = sizeof(T) == 2 ? 32 : 16;
+    if (cout % 128 == 0) return launch_conv<2, 2, true, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
+    return launch_conv<4, 1, true, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
 }
 
 }  // namespace holo
@@ -422,61 +509,38 @@ size_t holo_conv3x3_packed_elems(int cout, int cin) { return (size_t)9 * (size_t
 size_t holo_convt2x2_packed_elems(int cin, int cout) { return (size_t)4 * (size_t)cin * (size_t)cout; }
 
 int holo_pack_conv3x3_weight_f32(const float* w_oihw, float* w_packed, int cout, int cin, void* stream) {
-    using namespace holo;
-    HOLO_REQUIRE(w_oihw && w_packed, HOLO_ERR_ARG, "holo_pack_conv3x3_weight_f32: null pointer");
-    HOLO_REQUIRE(cin > 0 && cout > 0 && cin % kKC == 0, HOLO_ERR_ARG,
-                 "holo_pack_conv3x3_weight_f32: Cin=%d must be a positive multiple of 16 (Cout=%d)", cin, cout);
-    const long total = (long)9 * cin * cout;
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       w_oihw, w_packed, cout, cin, conv_kc(cin, cout, false));
-    return check_launch("holo_pack_conv3x3_weight_f32");
+    return holo::pack3x3_entry<float>(w_oihw, w_packed, cout, cin, stream);
 }
-
 int holo_pack_convt2x2_weight_f32(const float* w_iohw, float* w_packed, int cin, int cout, void* stream) {
-    using namespace holo;
-    HOLO_REQUIRE(w_iohw && w_packed, HOLO_ERR_ARG, "holo_pack_convt2x2_weight_f32: null pointer");
-    HOLO_REQUIRE(cin > 0 && cout > 0 && cin % kKC == 0, HOLO_ERR_ARG,
-                 "holo_pack_convt2x2_weight_f32: Cin=%d must be a positive multiple of 16 (Cout=%d)", cin, cout);
-    const long total = (long)4 * cin * cout;
-    hipLaunchKernelGGL(pack_convt2x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       w_iohw, w_packed, cin, cout, conv_kc(cin, cout, true));
-    return check_launch("holo_pack_convt2x2_weight_f32");
+    return holo::packt2x2_entry<float>(w_iohw, w_packed, cin, cout, stream);
 }
-
 int holo_conv3x3_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc, int batch, int h,
                      int w, int cin, int cout, int relu, int pool, void* stream) {
-    using namespace holo;
-    HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc, HOLO_ERR_ARG, "holo_conv3x3_f32: null pointer");
-    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG,
-                 "holo_conv3x3_f32: batch=%d h=%d w=%d (reflection padding needs h,w >= 2)", batch, h, w);
-    HOLO_REQUIRE(cin > 0 && cin % kKC == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
-                 "holo_conv3x3_f32: Cin=%d must be a multiple of 16 and Cout=%d of 64", cin, cout);
-    HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_f32: fused pooling requires relu");
-    HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
-                 "holo_conv3x3_f32: one image must stay below 2^31 elements");
-    hipStream_t s = as_stream(stream);
-    if (cout % 128 == 0) {
-        if (conv_kc(cin, cout, false) == 32)
-            return launch_conv<2, 2, false, 32>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
-        return launch_conv<2, 2, false, 16>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
-    }
-    return launch_conv<4, 1, false, 16>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+    return holo::conv3x3_entry<float>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, stream);
 }
-
 int holo_convt2x2_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc, int batch, int h,
                       int w, int cin, int cout, int relu, void* stream) {
-    using namespace holo;
-    HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc, HOLO_ERR_ARG, "holo_convt2x2_f32: null pointer");
-    HOLO_REQUIRE(batch > 0 && h >= 1 && w >= 1, HOLO_ERR_ARG, "holo_convt2x2_f32: batch=%d h=%d w=%d", batch, h, w);
-    HOLO_REQUIRE(cin > 0 && cin % kKC == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
-                 "holo_convt2x2_f32: Cin=%d must be a multiple of 16 and Cout=%d of 64", cin, cout);
-    HOLO_REQUIRE((long)h * w * 4 * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
-                 "holo_convt2x2_f32: one image must stay below 2^31 elements");
-    // N = 4*Cout is always a multiple of 128 here (Cout % 64 == 0 -> a 128-wide tile may straddle two
-    // (dy,dx) quadrants only if Cout % 128 != 0; then use the 64-wide tile)
-    hipStream_t s = as_stream(stream);
-    if (cout % 128 == 0) return launch_conv<2, 2, true, 16>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
-    return launch_conv<4, 1, true, 16>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
+    return holo::convt2x2_entry<float>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, stream);
+}
+
+// bf16 activations / weights (uint16_t storage), fp32 bias and accumulation
+int holo_pack_conv3x3_weight_bf16(const float* w_oihw, uint16_t* w_packed, int cout, int cin, void* stream) {
+    return holo::pack3x3_entry<holo::bf16_t>(w_oihw, reinterpret_cast<holo::bf16_t*>(w_packed), cout, cin, stream);
+}
+int holo_pack_convt2x2_weight_bf16(const float* w_iohw, uint16_t* w_packed, int cin, int cout, void* stream) {
+    return holo::packt2x2_entry<holo::bf16_t>(w_iohw, reinterpret_cast<holo::bf16_t*>(w_packed), cin, cout, stream);
+}
+int holo_conv3x3_bf16(const uint16_t* x_nhwc, const uint16_t* w_packed, const float* bias, uint16_t* y_nhwc, int batch,
+                      int h, int w, int cin, int cout, int relu, int pool, void* stream) {
+    using holo::bf16_t;
+    return holo::conv3x3_entry<bf16_t>(reinterpret_cast<const bf16_t*>(x_nhwc), reinterpret_cast<const bf16_t*>(w_packed), bias,
+                                       reinterpret_cast<bf16_t*>(y_nhwc), batch, h, w, cin, cout, relu, pool, stream);
+}
+int holo_convt2x2_bf16(const uint16_t* x_nhwc, const uint16_t* w_packed, const float* bias, uint16_t* y_nhwc, int batch,
+                       int h, int w, int cin, int cout, int relu, void* stream) {
+    using holo::bf16_t;
+    return holo::convt2x2_entry<bf16_t>(reinterpret_cast<const bf16_t*>(x_nhwc), reinterpret_cast<const bf16_t*>(w_packed), bias,
+                                        reinterpret_cast<bf16_t*>(y_nhwc), batch, h, w, cin, cout, relu, stream);
 }
 
 }  // extern "C"

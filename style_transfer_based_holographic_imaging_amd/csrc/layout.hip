@@ -24,6 +24,20 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = (TO)(float)in[i];
+}
+
+template <typename TI, typename TO>
+static int launch_cast(const TI* x, TO* y, long n, hipStream_t s, const char* what) {
+    HOLO_REQUIRE(x && y && n > 0, HOLO_ERR_ARG, "%s: null pointer or empty", what);
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((cast_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, s, x, y, n);
+    return check_launch(what);
+}
+
 static int launch_transpose(const float* x, float* y, int batch, int rows, int cols, hipStream_t s, const char* what) {
     HOLO_REQUIRE(x && y, HOLO_ERR_ARG, "%s: null pointer", what);
     HOLO_REQUIRE(batch > 0 && batch <= 65535 && rows > 0 && cols > 0, HOLO_ERR_ARG, "%s: batch=%d rows=%d cols=%d", what,
@@ -42,5 +56,11 @@ int holo_nhwc_to_nchw_f32(const float* x, float* y, int batch, int hw, int c, vo
 }
 int holo_nchw_to_nhwc_f32(const float* x, float* y, int batch, int hw, int c, void* stream) {
     return holo::launch_transpose(x, y, batch, c, hw, holo::as_stream(stream), "holo_nchw_to_nhwc_f32");
+}
+int holo_cast_f32_to_bf16(const float* x, uint16_t* y, long n, void* stream) {
+    return holo::launch_cast(x, reinterpret_cast<__bf16*>(y), n, holo::as_stream(stream), "holo_cast_f32_to_bf16");
+}
+int holo_cast_bf16_to_f32(const uint16_t* x, float* y, long n, void* stream) {
+    return holo::launch_cast(reinterpret_cast<const __bf16*>(x), y, n, holo::as_stream(stream), "holo_cast_bf16_to_f32");
 }
 }

@@ -92,8 +92,9 @@ def compile_plan(children):
 class Plan:
     """Executable plan of one child list; owns the packed-weight cache."""
 
-    def __init__(self, children):
+    def __init__(self, children, dtype=torch.float32):
         self.steps = compile_plan(list(children))
+        self.dtype = dtype          # activation / packed-weight dtype: float32 (exact fp32 MFMA) or bfloat16
         self._packed = {}
 
     def _weights(self, idx, step):
@@ -105,9 +106,9 @@ class Plan:
         w = conv.weight.detach()
         b = conv.bias.detach().float().contiguous()
         if step.kind == "conv":
-            vals = (ops.pack_conv3x3(w), b)
+            vals = (ops.pack_conv3x3(w, self.dtype), b)
         elif step.kind == "convt":
-            vals = (ops.pack_convt2x2(w), b)
+            vals = (ops.pack_convt2x2(w, self.dtype), b)
         elif step.kind == "first":
             c0 = step.conv0
             vals = (c0.weight.detach().float().contiguous(), c0.bias.detach().float().contiguous(),
@@ -127,7 +128,9 @@ class Plan:
         if st.kind == "first":
             if x.dim() != 4 or x.shape[1] != 1:
                 raise RuntimeError(f"the encoder expects a (B,1,H,W) hologram amplitude, got {tuple(x.shape)}")
-            return ops.conv_first(x, *wts)
+            return ops.conv_first(x, *wts, out_dtype=self.dtype)
+        if st.kind in ("conv", "convt") and x.dtype != self.dtype:
+            x = ops.cast(x, self.dtype)
         if st.kind == "conv":
             return ops.conv3x3(x, wts[0], wts[1], st.conv.out_channels, st.relu, st.pool)
         if st.kind == "convt":
@@ -149,10 +152,19 @@ class HoloSequential(nn.Sequential):
     channels-last view of the NHWC result, or the contiguous (B,2,H,W) planes of the last decoder
     layer.  CPU tensors raise: this path has no CPU fallback."""
 
+    def set_compute_dtype(self, dtype):
+        """float32 (default: exact fp32 MFMA, the 1e-4 parity path) or bfloat16 (BASELINE config 3: bf16 convs,
+        fp32 accumulation, statistics, distance head and propagator)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"compute dtype must be float32 or bfloat16, got {dtype}")
+        object.__setattr__(self, "_holo_dtype", dtype)
+        return self
+
     def _plan(self):
-        sig = tuple(id(m) for m in self)
+        dtype = getattr(self, "_holo_dtype", torch.float32)
+        sig = (tuple(id(m) for m in self), dtype)
         if getattr(self, "_holo_plan_sig", None) != sig:
-            object.__setattr__(self, "_holo_plan", Plan(list(self)))
+            object.__setattr__(self, "_holo_plan", Plan(list(self), dtype))
             object.__setattr__(self, "_holo_plan_sig", sig)
         return self._holo_plan
 

@@ -36,6 +36,34 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _sfx(t):
+    """C-ABI suffix of an activation tensor's dtype: the bf16 entry points mirror the f32 ones."""
+    if t.dtype == torch.bfloat16:
+        return "bf16"
+    if t.dtype == torch.float32:
+        return "f32"
+    raise RuntimeError(f"activations must be float32 or bfloat16, got {t.dtype}")
+
+
+def _actc(t):
+    """activation tensor: keep bf16, anything else becomes fp32; contiguous"""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def cast(x: torch.Tensor, dtype) -> torch.Tensor:
+    """fp32 <-> bf16 conversion by our kernel (round to nearest even)."""
+    _req(x)
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    name = "holo_cast_f32_to_bf16" if dtype == torch.bfloat16 else "holo_cast_bf16_to_f32"
+    _launch(name, lambda: getattr(lib, name)(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), nbytes=6.0 * x.numel())
+    return y
+
+
 class KernelTimer:
     """Per-launch timing with HIP events on the launch stream (torch's current stream is the stream
     handed to the C-ABI).  Use as a context manager around the region to measure; ``summary()``
@@ -92,13 +120,15 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     _req(x)
     assert x.dim() == 4
     b, c, h, w = x.shape
-    if x.dtype != torch.float32:
+    if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
     v = x.permute(0, 2, 3, 1)
     if v.is_contiguous():
         return v
     if c == 1:
         return x.contiguous().view(b, h, w, 1)
+    if x.dtype == torch.bfloat16:
+        return cast(to_nhwc(cast(x, torch.float32)), torch.bfloat16)
     x = x.contiguous()
     y = torch.empty((b, h, w, c), dtype=torch.float32, device=x.device)
     _launch("holo_nchw_to_nhwc_f32", lambda: lib.holo_nchw_to_nhwc_f32(x.data_ptr(), y.data_ptr(), b, h * w, c, _stream()), nbytes=8.0 * b * h * w * c)
@@ -117,39 +147,43 @@ def to_nchw_contiguous(x_nhwc: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # weights
 # ---------------------------------------------------------------------------------------------
-def pack_conv3x3(w_oihw: torch.Tensor) -> torch.Tensor:
+def pack_conv3x3(w_oihw: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     _req(w_oihw)
     cout, cin, kh, kw = w_oihw.shape
     assert (kh, kw) == (3, 3)
     w = _f32c(w_oihw.detach())
-    out = torch.empty(lib.holo_conv3x3_packed_elems(cout, cin), dtype=torch.float32, device=w.device)
-    check(lib.holo_pack_conv3x3_weight_f32(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "holo_pack_conv3x3_weight_f32")
+    out = torch.empty(lib.holo_conv3x3_packed_elems(cout, cin), dtype=dtype, device=w.device)
+    name = "holo_pack_conv3x3_weight_" + _sfx(out)
+    _launch(name, lambda: getattr(lib, name)(w.data_ptr(), out.data_ptr(), cout, cin, _stream()))
     return out
 
 
-def pack_convt2x2(w_iohw: torch.Tensor) -> torch.Tensor:
+def pack_convt2x2(w_iohw: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     _req(w_iohw)
     cin, cout, kh, kw = w_iohw.shape
     assert (kh, kw) == (2, 2)
     w = _f32c(w_iohw.detach())
-    out = torch.empty(lib.holo_convt2x2_packed_elems(cin, cout), dtype=torch.float32, device=w.device)
-    check(lib.holo_pack_convt2x2_weight_f32(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "holo_pack_convt2x2_weight_f32")
+    out = torch.empty(lib.holo_convt2x2_packed_elems(cin, cout), dtype=dtype, device=w.device)
+    name = "holo_pack_convt2x2_weight_" + _sfx(out)
+    _launch(name, lambda: getattr(lib, name)(w.data_ptr(), out.data_ptr(), cin, cout, _stream()))
     return out
 
 
 # ---------------------------------------------------------------------------------------------
-# convolutions
+# convolutions (activation dtype float32 or bfloat16 selects the _f32 / _bf16 entry point)
 # ---------------------------------------------------------------------------------------------
-def conv_first(x: torch.Tensor, w0, b0, w1, b1) -> torch.Tensor:
+def conv_first(x: torch.Tensor, w0, b0, w1, b1, out_dtype=torch.float32) -> torch.Tensor:
     """vgg[0:4] (net.py:77-80): (B,1,H,W) -> NHWC (B,H,W,64)."""
     _req(x, w0, b0, w1, b1)
     b, c, h, w = x.shape
     assert c == 1 and tuple(w0.shape) == (3, 1, 1, 1) and tuple(w1.shape) == (64, 3, 3, 3)
     x = _f32c(x)
-    y = torch.empty((b, h, w, 64), dtype=torch.float32, device=x.device)
-    _launch("holo_conv_first_f32", lambda: lib.holo_conv_first_f32(x.data_ptr(), _f32c(w0.detach()).data_ptr(), _f32c(b0.detach()).data_ptr(),
-                                  _f32c(w1.detach()).data_ptr(), _f32c(b1.detach()).data_ptr(), y.data_ptr(),
-                                  b, h, w, _stream()), flops=2.0 * (27 * 64 + 3) * b * h * w, nbytes=4.0 * b * h * w * 65)
+    y = torch.empty((b, h, w, 64), dtype=out_dtype, device=x.device)
+    name = "holo_conv_first_" + _sfx(y)
+    w0c, b0c, w1c, b1c = (_f32c(t.detach()) for t in (w0, b0, w1, b1))
+    _launch(name, lambda: getattr(lib, name)(x.data_ptr(), w0c.data_ptr(), b0c.data_ptr(), w1c.data_ptr(), b1c.data_ptr(),
+                                             y.data_ptr(), b, h, w, _stream()),
+            flops=2.0 * (27 * 64 + 3) * b * h * w, nbytes=b * h * w * (4.0 + 64 * y.element_size()))
     return y
 
 
@@ -157,11 +191,16 @@ def conv3x3(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, co
     """ReflectionPad2d(1)+Conv2d(3x3)[+ReLU][+MaxPool2d(2,2,ceil_mode=True)] on NHWC."""
     _req(x_nhwc, w_packed, bias)
     b, h, w, cin = x_nhwc.shape
-    x_nhwc = _f32c(x_nhwc)
+    x_nhwc = _actc(x_nhwc)
+    if w_packed.dtype != x_nhwc.dtype:
+        raise RuntimeError(f"packed weights are {w_packed.dtype} but activations {x_nhwc.dtype}")
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
-    y = torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x_nhwc.device)
-    _launch("holo_conv3x3_f32", lambda: lib.holo_conv3x3_f32(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, cin,
-                               cout, int(relu), int(pool), _stream()), flops=2.0 * 9 * cin * cout * b * h * w, nbytes=4.0 * b * (h * w * cin + ho * wo * cout))
+    y = torch.empty((b, ho, wo, cout), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    name = "holo_conv3x3_" + _sfx(x_nhwc)
+    es = x_nhwc.element_size()
+    _launch(name, lambda: getattr(lib, name)(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w,
+                                             cin, cout, int(relu), int(pool), _stream()),
+            flops=2.0 * 9 * cin * cout * b * h * w, nbytes=float(es) * b * (h * w * cin + ho * wo * cout))
     return y
 
 
@@ -169,22 +208,29 @@ def convt2x2(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, c
     """ConvTranspose2d(k=2,s=2)[+ReLU] on NHWC: (B,H,W,Cin) -> (B,2H,2W,Cout)."""
     _req(x_nhwc, w_packed, bias)
     b, h, w, cin = x_nhwc.shape
-    x_nhwc = _f32c(x_nhwc)
-    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x_nhwc.device)
-    _launch("holo_convt2x2_f32", lambda: lib.holo_convt2x2_f32(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, cin,
-                                cout, int(relu), _stream()), flops=2.0 * cin * 4 * cout * b * h * w, nbytes=4.0 * b * h * w * (cin + 4 * cout))
+    x_nhwc = _actc(x_nhwc)
+    if w_packed.dtype != x_nhwc.dtype:
+        raise RuntimeError(f"packed weights are {w_packed.dtype} but activations {x_nhwc.dtype}")
+    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    name = "holo_convt2x2_" + _sfx(x_nhwc)
+    es = x_nhwc.element_size()
+    _launch(name, lambda: getattr(lib, name)(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w,
+                                             cin, cout, int(relu), _stream()),
+            flops=2.0 * cin * 4 * cout * b * h * w, nbytes=float(es) * b * h * w * (cin + 4 * cout))
     return y
 
 
 def conv_last(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """decoder[36:38] (net.py:72-73): NHWC (B,H,W,64) -> NCHW (B,2,H,W)."""
+    """decoder[36:38] (net.py:72-73): NHWC (B,H,W,64) -> NCHW fp32 (B,2,H,W)."""
     _req(x_nhwc, w_oihw, bias)
     b, h, w, cin = x_nhwc.shape
     assert cin == 64 and tuple(w_oihw.shape) == (2, 64, 3, 3)
-    x_nhwc = _f32c(x_nhwc)
+    x_nhwc = _actc(x_nhwc)
     y = torch.empty((b, 2, h, w), dtype=torch.float32, device=x_nhwc.device)
-    _launch("holo_conv_last_f32", lambda: lib.holo_conv_last_f32(x_nhwc.data_ptr(), _f32c(w_oihw.detach()).data_ptr(), _f32c(bias.detach()).data_ptr(),
-                                 y.data_ptr(), b, h, w, _stream()), flops=2.0 * 9 * 64 * 2 * b * h * w, nbytes=4.0 * b * h * w * 66)
+    name = "holo_conv_last_" + _sfx(x_nhwc)
+    wc, bc = _f32c(w_oihw.detach()), _f32c(bias.detach())
+    _launch(name, lambda: getattr(lib, name)(x_nhwc.data_ptr(), wc.data_ptr(), bc.data_ptr(), y.data_ptr(), b, h, w, _stream()),
+            flops=2.0 * 9 * 64 * 2 * b * h * w, nbytes=b * h * w * (64.0 * x_nhwc.element_size() + 8))
     return y
 
 
@@ -192,14 +238,15 @@ def conv_last(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor) ->
 # statistics / AdaIN
 # ---------------------------------------------------------------------------------------------
 def channel_mean_std(x_nhwc: torch.Tensor, eps: float = 1e-5):
-    """function.py:4-12 on NHWC: returns (mean, std) of shape (B,C)."""
+    """function.py:4-12 on NHWC: returns fp32 (mean, std) of shape (B,C)."""
     _req(x_nhwc)
     b, h, w, c = x_nhwc.shape
-    x_nhwc = _f32c(x_nhwc)
+    x_nhwc = _actc(x_nhwc)
     mean = torch.empty((b, c), dtype=torch.float32, device=x_nhwc.device)
     std = torch.empty_like(mean)
-    _launch("holo_channel_mean_std_f32", lambda: lib.holo_channel_mean_std_f32(x_nhwc.data_ptr(), mean.data_ptr(), std.data_ptr(), b, h * w, c, float(eps),
-                                        _stream()), nbytes=4.0 * b * h * w * c)
+    name = "holo_channel_mean_std_" + _sfx(x_nhwc)
+    _launch(name, lambda: getattr(lib, name)(x_nhwc.data_ptr(), mean.data_ptr(), std.data_ptr(), b, h * w, c, float(eps), _stream()),
+            nbytes=float(x_nhwc.element_size()) * b * h * w * c)
     return mean, std
 
 
@@ -207,14 +254,16 @@ def adain_apply(x_nhwc, mean, std, style_mean, style_std, alpha: float = 1.0):
     """net.py:241-246.  style_mean/style_std: (1,C) (broadcast) or (B,C)."""
     _req(x_nhwc, mean, std, style_mean, style_std)
     b, h, w, c = x_nhwc.shape
-    x_nhwc = _f32c(x_nhwc)
+    x_nhwc = _actc(x_nhwc)
     style_mean = _f32c(style_mean.reshape(-1, c))
     style_std = _f32c(style_std.reshape(-1, c))
     assert style_mean.shape == style_std.shape and style_mean.shape[0] in (1, b)
     stride = 0 if style_mean.shape[0] == 1 and b != 1 else c
     y = torch.empty_like(x_nhwc)
-    _launch("holo_adain_apply_f32", lambda: lib.holo_adain_apply_f32(x_nhwc.data_ptr(), mean.data_ptr(), std.data_ptr(), style_mean.data_ptr(),
-                                   style_std.data_ptr(), stride, float(alpha), y.data_ptr(), b, h * w, c, _stream()), nbytes=8.0 * b * h * w * c)
+    name = "holo_adain_apply_" + _sfx(x_nhwc)
+    _launch(name, lambda: getattr(lib, name)(x_nhwc.data_ptr(), mean.data_ptr(), std.data_ptr(), style_mean.data_ptr(),
+                                             style_std.data_ptr(), stride, float(alpha), y.data_ptr(), b, h * w, c, _stream()),
+            nbytes=2.0 * x_nhwc.element_size() * b * h * w * c)
     return y
 
 

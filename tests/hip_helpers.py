@@ -38,3 +38,40 @@ def cplx_rel(a, b):
     a = torch.view_as_real(a.detach().cpu().to(torch.complex128))
     b = torch.view_as_real(b.detach().cpu().to(torch.complex128))
     return float((a - b).abs().max() / b.abs().max())
+
+
+def bf16_emulated_field_retrieval(content, style, sds, alpha=1.0):
+    """CPU emulation of the bf16 conv path: weights and every activation that the HIP path stores as bf16
+    are rounded to bf16 (fp32 math in between, as the MFMA accumulates), statistics / last layer / distance
+    head in fp32.  Test infrastructure (uses the oracle's layer tables)."""
+    import torch.nn.functional as F
+    vgg, dec, dist = sds
+
+    def r(t):
+        return t.to(torch.bfloat16).float()
+
+    x = content
+    for step in orc.ENCODER_PLAN:
+        if step[0] == "conv1x1":
+            x = F.conv2d(x, vgg[f"{step[1]}.weight"], vgg[f"{step[1]}.bias"])          # fused into conv_first (fp32)
+        elif step[0] == "conv":
+            w = vgg[f"{step[1]}.weight"]
+            w = w if step[1] == 2 else r(w)                                             # conv_first keeps fp32 weights
+            x = F.relu(orc._conv3x3_reflect(x, w, vgg[f"{step[1]}.bias"]))
+            nxt_is_pool = orc.ENCODER_PLAN[orc.ENCODER_PLAN.index(step) + 1][0] == "pool" if step != orc.ENCODER_PLAN[-1] else False
+            if not nxt_is_pool:
+                x = r(x)
+        else:
+            x = r(F.max_pool2d(x, 2, 2, 0, ceil_mode=True))                             # pool is fused before the store
+    mean, std = orc.calc_mean_std(x)
+    t = r(orc.adain_with_style_vector(x, style, alpha))
+    y = t
+    for step in orc.DECODER_PLAN:
+        w, b = dec[f"{step[1]}.weight"], dec[f"{step[1]}.bias"]
+        if step[0] == "conv" and step[2]:
+            y = r(F.relu(orc._conv3x3_reflect(y, r(w), b)))
+        elif step[0] == "conv":
+            y = orc._conv3x3_reflect(y, w, b)                                           # conv_last: fp32 weights, fp32 out
+        else:
+            y = r(F.relu(F.conv_transpose2d(y, r(w), b, stride=2)))
+    return y[:, :1], y[:, 1:], orc.distance_head(mean, std, dist)

@@ -62,9 +62,28 @@ def gather_to_root(packed: torch.Tensor, counts: list[int] | None = None, dst: i
     if packed.shape[0] < rows:
         pad = torch.zeros((rows - packed.shape[0], packed.shape[1]), dtype=packed.dtype, device=packed.device)
         packed = torch.cat([packed, pad], 0)
-    if rank == dst:
-        out = torch.empty((world, rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
-        dist.gather(packed, list(out.unbind(0)), dst=dst)
-        return torch.cat([out[r, :counts[r]] for r in range(world)], 0)
-    dist.gather(packed, None, dst=dst)
-    return None
+    global _GATHER_UNSUPPORTED
+    if not _GATHER_UNSUPPORTED:
+        try:
+            if rank == dst:
+                out = torch.empty((world, rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+                dist.gather(packed, list(out.unbind(0)), dst=dst)
+                return out[0] if world == 1 else _trim(out, counts)
+            dist.gather(packed, None, dst=dst)
+            return None
+        except (RuntimeError, NotImplementedError) as e:   # a backend without gather: every rank sees the same error
+            _GATHER_UNSUPPORTED = True
+            if rank == dst:
+                print(f"[shard] dist.gather unavailable ({type(e).__name__}); using all_gather_into_tensor", flush=True)
+    out = torch.empty((world, rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed)
+    return _trim(out, counts) if rank == dst else None
+
+
+_GATHER_UNSUPPORTED = False
+
+
+def _trim(out, counts):
+    if all(c == out.shape[1] for c in counts):
+        return out.reshape(-1, out.shape[2])
+    return torch.cat([out[r, :counts[r]] for r in range(out.shape[0])], 0)

@@ -432,9 +432,12 @@ __global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict_
 #ifndef HOLO_CONV_KC32
 #define HOLO_CONV_KC32 0
 #endif
+#ifndef HOLO_CONV_BF16_KC64
+#define HOLO_CONV_BF16_KC64 1   // bf16, 128-wide tile: 64-channel stages (128-B LDS rows): twice the MFMAs per barrier
+#endif
 template <typename T>
 static int conv_kc(int cin, int cout, bool convt) {
-    if (sizeof(T) == 2) return 32;
+    if (sizeof(T) == 2) return (HOLO_CONV_BF16_KC64 && !convt && cout % 128 == 0 && cin % 64 == 0) ? 64 : 32;
     return (HOLO_CONV_KC32 && !convt && cout % 128 == 0 && cin % 32 == 0) ? 32 : 16;
 }
 template <typename T> constexpr int min_cin() { return sizeof(T) == 2 ? 32 : 16; }
@@ -478,8 +481,8 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
     hipStream_t s = as_stream(stream);
     constexpr int KCD = sizeof(T) == 2 ? 32 : 16;   // default K chunk of the dtype
     if (cout % 128 == 0) {
-        if (sizeof(T) == 4 && conv_kc<T>(cin, cout, false) == 32)
-            return launch_conv<2, 2, false, 32, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+        if (conv_kc<T>(cin, cout, false) == 2 * KCD)   // the deeper-stage variant of this dtype
+            return launch_conv<2, 2, false, 2 * KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
         return launch_conv<2, 2, false, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
     }
     return launch_conv<4, 1, false, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);

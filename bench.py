@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=4, help="holograms in the CPU baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
+    ap.add_argument("--distances", type=int, default=1,
+                    help="propagate every retrieved field to N distances in one sweep (BASELINE configs[4] uses 8)")
+    ap.add_argument("--style", default="MNIST", help="style_representation/<name>/style_vector.pt")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="conv stack arithmetic: f32 = exact fp32 MFMA (BASELINE configs[1], the parity path); "
                          "bf16 = bf16 MFMA with fp32 accumulation (configs[2]); the propagator is fp32 either way")
@@ -129,7 +132,7 @@ def main():
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     from holo_oracle import HoloParams
     model_forward = Holo_Generator(HoloParams())
-    style_cpu = torch.load(os.path.join(REPO, "style_representation", "MNIST", "style_vector.pt"), map_location="cpu").float()
+    style_cpu = torch.load(os.path.join(REPO, "style_representation", args.style, "style_vector.pt"), map_location="cpu").float()
     style = style_cpu.to(dev)
 
     # synthetic input, SURVEY.md §8d config 2: phase objects -> holograms by forward propagation (on the GPU)
@@ -142,11 +145,16 @@ def main():
         content = torch.sqrt(model_forward(torch.full_like(ph, 0.6), ph, d_content)).contiguous()
     del ph
 
+    sweep_d = torch.linspace(-0.1, -0.8, max(args.distances, 2), device=dev)[:args.distances]
+
     def step():
         with torch.no_grad():
             amp, p, d = field_retrieval(network, content, style, 1.0, True)
-            a_f, p_f = model_forward(amp, p * 1.0, -d_style, return_field=True, unwrap=False)
-            if world > 1:
+            if args.distances > 1:   # utils/Data_loader.py:59-62 idiom: one field, a list of distances
+                a_f, p_f = model_forward.sweep(amp, p * 1.0, sweep_d)
+            else:
+                a_f, p_f = model_forward(amp, p * 1.0, -d_style, return_field=True, unwrap=False)
+            if world > 1 and args.distances == 1:
                 shard.gather_to_root(shard.pack_outputs(amp, p, a_f, p_f, d))
         return amp, p, d, a_f, p_f
 
@@ -185,7 +193,7 @@ def main():
             "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: batch {b}/GPU synthetic {s}x{s} holograms, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 convs / fp32 FFT'}, VGG-AdaIN-decoder + "
                                    f"distance head + angular-spectrum back-propagation (P={2 * s}), seeded He-normal weights",
-                       "batch_per_gpu": b, "size": s, "parallelism": f"batch-sharded x{world}, one RCCL gather per step"},
+                       "batch_per_gpu": b, "size": s, "distances_per_field": args.distances, "style": args.style, "parallelism": f"batch-sharded x{world}, one RCCL gather per step"},
         }
         if timer is not None:
             summ = timer.summary()

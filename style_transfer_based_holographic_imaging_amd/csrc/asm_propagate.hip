@@ -193,7 +193,12 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
     const int tid = threadIdx.x;
     const int fo = blockIdx.y;          // output field = field * n_dist + dist
     const int f = fo / n_dist;
-    const int kx0 = blockIdx.x * CW;
+    // Column groups narrower than a 128-B line (CW < 16) share lines with their neighbours.  Blocks are dealt
+    // round-robin over the 8 XCDs (private L2s), so give each XCD a contiguous range of groups: the 128/(8*CW)
+    // blocks that touch one line then hit the same L2.  Bijective since P/CW is a multiple of 8; speed only.
+    int grp = blockIdx.x;
+    if (CW < 16 && (P / CW) % 8 == 0) grp = (blockIdx.x % 8) * ((P / CW) / 8) + blockIdx.x / 8;
+    const int kx0 = grp * CW;
     fft_fill_twiddles<P, -1>(twf, tid, THREADS);
     if (!SYM) fft_fill_twiddles<P, +1>(twi, tid, THREADS);
     // coalesced read of S rows x CW columns, transposed into per-column sequences (compact: S entries)

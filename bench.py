@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=4, help="holograms in the CPU baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a hipGraph (torch.cuda.CUDAGraph) and time K replays; the per-kernel "
+                         "roofline figures then come from K extra eager steps after the timed region")
     ap.add_argument("--distances", type=int, default=1,
                     help="propagate every retrieved field to N distances in one sweep (BASELINE configs[4] uses 8)")
     ap.add_argument("--style", default="MNIST", help="style_representation/<name>/style_vector.pt")
@@ -168,16 +171,33 @@ def main():
         step()
     sync()
     timer = None if args.no_events else ops.KernelTimer()
-    t0 = time.perf_counter()
-    if timer is not None:
-        with timer:
+    if args.graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = step()          # noqa: F841  (keeps the captured outputs alive)
+        graph.replay()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if timer is not None:           # eager pass for the per-kernel numbers only
+            with timer:
+                for _ in range(args.steps):
+                    step()
+            sync()
+    else:
+        t0 = time.perf_counter()
+        if timer is not None:
+            with timer:
+                for _ in range(args.steps):
+                    step()
+        else:
             for _ in range(args.steps):
                 step()
-    else:
-        for _ in range(args.steps):
-            step()
-    sync()
-    elapsed = time.perf_counter() - t0
+        sync()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,7 +213,7 @@ def main():
             "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: batch {b}/GPU synthetic {s}x{s} holograms, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16 convs / fp32 FFT'}, VGG-AdaIN-decoder + "
                                    f"distance head + angular-spectrum back-propagation (P={2 * s}), seeded He-normal weights",
-                       "batch_per_gpu": b, "size": s, "distances_per_field": args.distances, "style": args.style, "parallelism": f"batch-sharded x{world}, one RCCL gather per step"},
+                       "batch_per_gpu": b, "size": s, "distances_per_field": args.distances, "style": args.style, "hipgraph": bool(args.graph), "parallelism": f"batch-sharded x{world}, one RCCL gather per step"},
         }
         if timer is not None:
             summ = timer.summary()

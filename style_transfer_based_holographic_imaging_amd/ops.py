@@ -65,22 +65,33 @@ def cast(x: torch.Tensor, dtype) -> torch.Tensor:
 
 
 class KernelTimer:
-    """Per-launch timing with HIP events on the launch stream (torch's current stream is the stream
-    handed to the C-ABI).  Use as a context manager around the region to measure; ``summary()``
+    """Per-launch timing with HIP events on the launch stream (torch's current stream is the stream handed to
+    the C-ABI).  ONE event is recorded after every launch (plus one when the region opens); a launch's
+    duration is the difference of consecutive events, i.e. it includes the idle gap before the kernel —
+    half the events of start/stop pairs (pairs cost ~1 % of a 37 ms step).  Launches made by torch itself
+    between two of ours (a few tiny element-wise ops) are charged to our next launch.  ``summary()``
     synchronises and returns {name: dict(calls, ms, flops, bytes)} with ALGORITHMIC flops/bytes."""
 
     def __init__(self):
         self.records = []
+        self._last = None
 
     def __enter__(self):
         global _TIMER
         self._prev, _TIMER = _TIMER, self
+        self._last = torch.cuda.Event(enable_timing=True)
+        self._last.record()
         return self
 
     def __exit__(self, *exc):
         global _TIMER
         _TIMER = self._prev
         return False
+
+    def mark(self):
+        """restart the clock (e.g. after work that should not be charged to the next launch)"""
+        self._last = torch.cuda.Event(enable_timing=True)
+        self._last.record()
 
     def summary(self):
         torch.cuda.synchronize()
@@ -97,15 +108,19 @@ class KernelTimer:
 _TIMER = None
 
 
-def _launch(name, fn, flops=0.0, nbytes=0.0):
+def _launch(name, fn, flops=0.0, nbytes=0.0, fresh=False):
+    """fresh=True: start this launch's clock right before it (used where torch's own small element-wise launches
+    precede ours and must not be charged to the kernel's roofline figure)."""
     if _TIMER is None:
         check(fn(), name)
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    if fresh:
+        _TIMER.mark()
     check(fn(), name)
+    e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    _TIMER.records.append((name, float(flops), float(nbytes), e0, e1))
+    _TIMER.records.append((name, float(flops), float(nbytes), _TIMER._last, e1))
+    _TIMER._last = e1
 
 
 # ---------------------------------------------------------------------------------------------
@@ -398,5 +413,5 @@ def asm_propagate(in0, in1, phase_c, s, zero_padding, wavelength, pixel_size, ph
             (out1.data_ptr() + f0 * n_dist * plane * 4) if out1 is not None else 0, out_mode, plane, plane,
             phase_c.data_ptr() + f0 * n_dist * 8, nf, n_dist, s, int(bool(zero_padding)),
             float(wavelength), float(pixel_size), float(phase_scale), ws.data_ptr(), ws_bytes, _stream()),
-                nbytes=(24.0 + 56.0 * n_dist) * plane * nf)
+                nbytes=(24.0 + 56.0 * n_dist) * plane * nf, fresh=True)
     return out0, out1

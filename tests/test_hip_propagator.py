@@ -144,3 +144,41 @@ def test_rejects_unsupported_sizes(hg, dev):
         hg(torch.ones(1, 1, 2050, 2050, device=dev), torch.zeros(1, 1, 2050, 2050, device=dev), 0.3)
     with pytest.raises(RuntimeError, match="ROCm device"):
         hg(torch.ones(1, 1, 32, 32), torch.zeros(1, 1, 32, 32), 0.3)
+
+
+def test_batch_chunking_and_odd_layouts(hg, dev, monkeypatch):
+    """Large batches are processed in groups sized for the Infinity Cache; force tiny groups and compare.
+    Also: non-contiguous amplitude/phase (transposed views) and a float64 distance tensor."""
+    from style_transfer_based_holographic_imaging_amd import ops
+    g = torch.Generator().manual_seed(12)
+    amp = (torch.rand(7, 1, 64, 64, generator=g) + 0.2).to(dev)
+    ph = (torch.rand(7, 1, 64, 64, generator=g) * 4 - 2).to(dev)
+    d = torch.linspace(0.2, 0.8, 7).view(-1, 1, 1, 1).to(dev)
+    a_ref, p_ref = hg(amp, ph, d, return_field=True)
+    monkeypatch.setattr(ops, "_ASM_CACHE_BUDGET", 3 * 64 * 128 * 8 * 2)      # 3 fields per launch group
+    a_c, p_c = hg(amp, ph, d, return_field=True)
+    assert torch.equal(a_c, a_ref) and torch.equal(p_c, p_ref)
+    sw_ref = hg.sweep(amp[:5], ph[:5], [-0.1, -0.3, -0.5])                    # 5 fields x 3 distances, 1 per group
+    monkeypatch.setattr(ops, "_ASM_CACHE_BUDGET", 1)
+    sw_c = hg.sweep(amp[:5], ph[:5], [-0.1, -0.3, -0.5])
+    assert torch.equal(sw_c[0], sw_ref[0]) and torch.equal(sw_c[1], sw_ref[1])
+    monkeypatch.undo()
+    a_t, p_t = hg(amp.transpose(-1, -2), ph.transpose(-1, -2), d, return_field=True)   # strided planes -> copied
+    a_tc, p_tc = hg(amp.transpose(-1, -2).contiguous(), ph.transpose(-1, -2).contiguous(), d, return_field=True)
+    assert torch.equal(a_t, a_tc) and torch.equal(p_t, p_tc)
+    a64, _ = hg(amp, ph, d.double(), return_field=True)                        # float64 distances: full-precision 2*pi*d
+    assert rel_err(a64.cpu(), a_ref.cpu()) < 1e-4
+
+
+def test_back_prop_module(dev):
+    import types
+    from hip_helpers import cplx_rel, orc
+    from utils.Forward_model import Back_prop
+    args = types.SimpleNamespace(amplitude_normalize=1.0, wavelength=532e-9, pixel_size=1.5e-6, distance_normalize=1.0,
+                                 distance_normalize_constant=0.0, Holo_G_input="re_im")
+    holo = torch.rand(2, 1, 64, 64, generator=torch.Generator().manual_seed(2)) + 0.1
+    d = torch.tensor([-0.4, -0.6]).view(-1, 1, 1, 1)
+    out = Back_prop(args)(holo.to(dev), d.to(dev))
+    ref = orc.asm(torch.sqrt(holo).to(torch.complex64), 532e-9, d * 1e-3, 1.5e-6, zero_padding=False)
+    assert out.shape == (2, 2, 64, 64)
+    assert cplx_rel(torch.complex(out[:, :1].float(), out[:, 1:].float()), ref) < 1e-5

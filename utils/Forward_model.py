@@ -63,3 +63,28 @@ class Holo_Generator(nn.Module):
         out0, out1 = ops.asm_propagate(amplitude, phase, phase_c, s, True, self.wavelength, self.pixel_size,
                                        self.phase_normalize, mode, n_dist=n)
         return (out0, out1) if return_field else out0
+
+
+class Back_prop(nn.Module):
+    """utils/Forward_model.py:42-65 of the reference (never instantiated by its scripts): sqrt(hologram) propagated
+    on the UN-padded grid, returned as [abs, angle] or [re, im] stacked on the channel axis."""
+
+    def __init__(self, args):
+        super(Back_prop, self).__init__()
+        self.amplitude_normalize = args.amplitude_normalize
+        self.wavelength = args.wavelength
+        self.pixel_size = args.pixel_size
+        self.distance_normalize = args.distance_normalize
+        self.distance_normalize_constant = args.distance_normalize_constant
+        self.input_type = args.Holo_G_input
+
+    def forward(self, holo, d):
+        from utils.Angular_Spectrum_Method import ASM
+        d = ((d + self.distance_normalize_constant) * self.distance_normalize) * 0.001
+        holo = torch.sqrt(holo)
+        o = ASM(holo, self.wavelength, d, self.pixel_size) * self.amplitude_normalize
+        if self.input_type == 'amp_pha':
+            r, i = torch.abs(o), torch.angle(o)
+        else:
+            r, i = torch.real(o), torch.imag(o)
+        return torch.cat([r, i], dim=1)

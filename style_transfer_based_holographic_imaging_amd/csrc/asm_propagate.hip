@@ -62,6 +62,28 @@ __device__ __forceinline__ void sincos_f32(float x, float* s, float* c) {
     sincos_poly(r, (int)n & 3, s, c);
 }
 
+// atan2 for the phase output: octant reduction + an odd polynomial of degree 15 on [0,1] (Chebyshev-interpolated
+// atan(a)/a in a^2; max error 1.5e-7 rad evaluated in fp32 — the fp32 FFT noise on the phase is ~1e-6); the
+// library atan2f was about half of the inverse row kernel's VALU instructions.  atan2(0,0) = 0 like the library.
+__device__ __forceinline__ float atan2_poly(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mx > 0.0f ? mn / mx : 0.0f;
+    const float s = a * a;
+    float r = -0.00455979211255908f;
+    r = fmaf(r, s, 0.023780519142746925f);
+    r = fmaf(r, s, -0.05882975459098816f);
+    r = fmaf(r, s, 0.09868865460157394f);
+    r = fmaf(r, s, -0.14003290235996246f);
+    r = fmaf(r, s, 0.19966961443424225f);
+    r = fmaf(r, s, -0.3333181142807007f);
+    r = fmaf(r, s, 0.9999998807907104f);
+    r = r * a;
+    if (ay > ax) r = 1.57079637f - r;
+    if (x < 0.0f) r = 3.14159274f - r;
+    return y < 0.0f ? -r : r;
+}
+
 __device__ __forceinline__ v2f load_field(const float* __restrict__ in0, const float* __restrict__ in1,
                                           int in_mode, long off0, long off1, float phase_scale) {
     if (in_mode == HOLO_ASM_IN_COMPLEX) return reinterpret_cast<const v2f*>(in0)[off0];
@@ -128,26 +150,37 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_fwd_kernel(
         const long f = valid ? row / S : 0;
         const int y = valid ? (int)(row % S) : 0;
         const long base0 = f * stride0 + (long)y * S, base1 = f * stride1 + (long)y * S;
+        // element index i = j + r*P/R1 with j < P/R1: the replicate-pad regions (Angular_Spectrum_Method.py:12) are
+        // whole r-slices.  Interior elements are loaded and packed first; the two edge values (columns 0 and S-1)
+        // are interior elements of the row's first / last lane, so they are broadcast instead of recomputed.
+        constexpr bool ONE_BFLY = (E == R1) && (G <= 64);
         v2f edge0 = {0.f, 0.f}, edge1 = edge0;
-        if (PAD) {  // F.pad(..., mode="replicate") along the row (Angular_Spectrum_Method.py:12)
+        if (PAD && !ONE_BFLY) {
             edge0 = load_field(in0, in1, in_mode, base0, base1, phase_scale);
             edge1 = load_field(in0, in1, in_mode, base0 + S - 1, base1 + S - 1, phase_scale);
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int r = e % R1;
-            // element index i = j + r*P/R1 with j < P/R1: the pad regions are whole r-slices
             const bool left = PAD && (r + 1) * 4 <= R1;
             const bool right = PAD && r * 4 >= 3 * R1;
-            if (left) {
-                v[e] = edge0;
-            } else if (right) {
-                v[e] = edge1;
-            } else {
+            if (!left && !right) {
                 const int i = fft_elem_index<P, G, R1>(t, e);
                 const int col = PAD ? i - S / 2 : i;
                 v[e] = load_field(in0, in1, in_mode, base0 + col, base1 + col, phase_scale);
             }
+        }
+        if (PAD && ONE_BFLY) {
+            // column 0 = element S/2 = lane 0, slot R1/4;  column S-1 = element 3S/2-1 = lane G-1, slot 3*R1/4-1
+            const v2f lo = v[R1 / 4], hi = v[3 * R1 / 4 - 1];
+            edge0 = v2f{__shfl(lo.x, 0, G), __shfl(lo.y, 0, G)};
+            edge1 = v2f{__shfl(hi.x, G - 1, G), __shfl(hi.y, G - 1, G)};
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r = e % R1;
+            if (PAD && (r + 1) * 4 <= R1) v[e] = edge0;
+            if (PAD && r * 4 >= 3 * R1) v[e] = edge1;
         }
     }
     __syncthreads();  // twiddle table
@@ -304,7 +337,7 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
             const long pix = (long)y * S + x;
             if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
                 out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
-                out1[fo * ostride1 + pix] = atan2f(o.y, o.x);
+                out1[fo * ostride1 + pix] = atan2_poly(o.y, o.x);
             } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
                 const float a = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
                 out0[fo * ostride0 + pix] = a * a;

@@ -212,13 +212,99 @@ struct ColCfg {
     static constexpr int WAVES_PER_SIMD = (BPC * THREADS) / 256 >= 1 ? (BPC * THREADS) / 256 : 1;
 };
 
+// One tile (output field x column group) per block: the configuration for P <= 512.
+template <int P, bool PAD>
+__global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void asm_cols_kernel(
+    const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const double* __restrict__ phase_const,
+    int n_dist, double inv_ppx, double lam2, double lamb, int ablate) {
+    using C = ColCfg<P>;
+    constexpr int S = PAD ? P / 2 : P;
+    constexpr int CW = C::CW, G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
+    constexpr int R1 = fft_radix<P, -1>(0);
+    constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);  // forward's last = inverse's first radix
+    static_assert(fft_radix<P, +1>(0) == RL && fft_radix<P, +1>(FftPlan<P>::n - 1) == R1, "plan symmetry");
+    constexpr bool SYM = fft_plan_symmetric<P>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* twf = reinterpret_cast<v2f*>(smem_raw);
+    v2f* twi = SYM ? twf : twf + tw_entries_fwd<P>();
+    v2f* cols = twf + C::TWN;
+
+    const int tid = threadIdx.x;
+    const int fo = blockIdx.y;          // output field = field * n_dist + dist
+    const int f = fo / n_dist;
+    // Column groups narrower than a 128-B line (CW < 16) share lines with their neighbours.  Blocks are dealt
+    // round-robin over the 8 XCDs (private L2s), so give each XCD a contiguous range of groups: the 128/(8*CW)
+    // blocks that touch one line then hit the same L2.  Bijective since P/CW is a multiple of 8; speed only.
+    int grp = blockIdx.x;
+    if (CW < 16 && (P / CW) % 8 == 0) grp = (blockIdx.x % 8) * ((P / CW) / 8) + blockIdx.x / 8;
+    const int kx0 = grp * CW;
+    fft_fill_twiddles<P, -1>(twf, tid, THREADS);
+    if (!SYM) fft_fill_twiddles<P, +1>(twi, tid, THREADS);
+    // coalesced read of S rows x CW columns, transposed into per-column sequences (compact: S entries)
+    const v2f* src = tbuf + (long)f * S * P + kx0;
+    for (int i = tid; i < S * CW; i += THREADS) {
+        const int y = i / CW, cl = i % CW;
+        cols[cl * PITCH + fft_pad(y)] = src[(long)y * P + cl];
+    }
+    __syncthreads();
+    const int col = tid / G, t = tid % G;
+    v2f* my = cols + col * PITCH;
+    v2f v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = fft_elem_index<P, G, R1>(t, e);
+        // replicate rows above/below the field are copies of its first/last row spectrum
+        int y = PAD ? i - S / 2 : i;
+        y = y < 0 ? 0 : (y > S - 1 ? S - 1 : y);
+        v[e] = my[fft_pad(y)];
+    }
+    if (!(ablate & 2)) fft_run<P, G, -1>(v, my, twf, t);   // spectrum in registers at ky = fft_elem_index<P,G,RL>(t,e)
+
+    // transfer function: one value per (column, |ky|), shared through LDS by rows ky and P-ky.  The column's
+    // LDS region is private to its G lanes (one wave or less): wave-local ordering, no block barrier.
+    fft_sync<G>();
+    {
+        // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
+        const double c_over_l = phase_const[fo] / lamb;
+        const int kx = kx0 + col;
+        const double fx = (double)(kx < P / 2 ? kx : kx - P) * inv_ppx;
+        const double fx2 = fx * fx;
+        for (int m = t; m <= P / 2; m += G) {
+            const double fy = (double)m * inv_ppx;
+            my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
+        }
+    }
+    fft_sync<G>();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int ky = fft_elem_index<P, G, RL>(t, e);
+        v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
+    }
+    if (!(ablate & 2)) fft_run<P, G, +1>(v, my, twi, t);
+
+    // keep the S centre rows; transpose back through LDS for a coalesced store
+    fft_sync<G>();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = fft_elem_index<P, G, R1>(t, e);
+        const int y = PAD ? i - S / 2 : i;
+        if (y >= 0 && y < S) my[fft_pad(y)] = v[e];
+    }
+    __syncthreads();
+    v2f* dst = ubuf + (long)fo * S * P + kx0;
+    for (int i = tid; i < S * CW; i += THREADS) {
+        const int y = i / CW, cl = i % CW;
+        dst[(long)y * P + cl] = cols[cl * PITCH + fft_pad(y)];
+    }
+}
+
 // A block loops over tiles (output field x column group) with a grid stride; in the persistent configuration
 // (ColCfg::PERSIST) it prefetches the NEXT tile's columns into registers while it transforms the current one, so
 // the memory phases of a tile overlap the arithmetic of its neighbour.  (At P = 512 the phases of the one-tile
 // blocks simply add up — 27 us copy skeleton + 23 us FFT passes + 6.5 us H = 58.5 us, ablation — but the
 // persistent form was not faster there.)
 template <int P, bool PAD>
-__global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void asm_cols_kernel(
+__global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void asm_cols_persistent_kernel(
     const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const double* __restrict__ phase_const,
     int n_dist, int n_tiles, double inv_ppx, double lam2, double lamb, int ablate) {
     using C = ColCfg<P>;
@@ -419,8 +505,12 @@ static int launch_asm(const AsmArgs& a) {
     static bool attr_done = false;  // idempotent; a race only repeats the call
     if (!attr_done) {
         if (col_lds > 48 * 1024)
+        {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_persistent_kernel<P, PAD>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
+        }
         if (row_lds_f > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_f);
@@ -435,12 +525,16 @@ static int launch_asm(const AsmArgs& a) {
                        reinterpret_cast<v2f*>(a.tbuf), rows_in);
     {
         const long n_tiles = (long)(P / C::CW) * a.n_fields * a.n_dist;
-        // persistent: one block per CU; otherwise one tile per block
-        const long resident = C::PERSIST ? 256L : n_tiles;
-        const unsigned grid = (unsigned)(n_tiles < resident ? n_tiles : resident);
-        hipLaunchKernelGGL((asm_cols_kernel<P, PAD>), dim3(grid), dim3(C::THREADS), col_lds, a.stream,
-                           reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
-                           (int)n_tiles, 1.0 / a.ppx, a.lam2, a.lamb, a.ablate);
+        if (C::PERSIST) {   // one block per CU, grid-stride over the tiles
+            const unsigned grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
+            hipLaunchKernelGGL((asm_cols_persistent_kernel<P, PAD>), dim3(grid), dim3(C::THREADS), col_lds, a.stream,
+                               reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const,
+                               a.n_dist, (int)n_tiles, 1.0 / a.ppx, a.lam2, a.lamb, a.ablate);
+        } else {
+            hipLaunchKernelGGL((asm_cols_kernel<P, PAD>), dim3(P / C::CW, a.n_fields * a.n_dist), dim3(C::THREADS), col_lds,
+                               a.stream, reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const,
+                               a.n_dist, 1.0 / a.ppx, a.lam2, a.lamb, a.ablate);
+        }
     }
     const long rows_out = rows_in * a.n_dist;
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)

@@ -182,3 +182,28 @@ def test_back_prop_module(dev):
     ref = orc.asm(torch.sqrt(holo).to(torch.complex64), 532e-9, d * 1e-3, 1.5e-6, zero_padding=False)
     assert out.shape == (2, 2, 64, 64)
     assert cplx_rel(torch.complex(out[:, :1].float(), out[:, 1:].float()), ref) < 1e-5
+
+
+@pytest.mark.parametrize("pn,dn,dc", [(1.0, 1.0, 0.0), (2.0, 0.5, 0.1), (0.5, 2.0, -0.05)])
+def test_holo_generator_normalisation_constants(dev, pn, dn, dc):
+    """phase_normalize / distance_normalize / distance_normalize_constant (Forward_model.py:9-20), tensor and
+    scalar distances, single- and two-channel fields, all three return modes, against the oracle."""
+    import types
+    from hip_helpers import cplx_rel, orc
+    from utils.Forward_model import Holo_Generator
+    hp = orc.HoloParams(phase_normalize=pn, distance_normalize=dn, distance_normalize_constant=dc)
+    args = types.SimpleNamespace(wavelength=hp.wavelength, pixel_size=hp.pixel_size, distance_normalize=dn,
+                                 distance_normalize_constant=dc, phase_normalize=pn)
+    hgp = Holo_Generator(args).to(dev)
+    g = torch.Generator().manual_seed(int(pn * 10 + dn * 100))
+    amp = torch.rand(3, 1, 32, 32, generator=g) + 0.2
+    ph = (torch.rand(3, 1, 32, 32, generator=g) - 0.5) * 3
+    d = torch.tensor([0.3, 0.5, -0.2]).view(-1, 1, 1, 1)
+    ref = orc.holo_generator(hp, amp, ph, d, complex_number=True)
+    assert cplx_rel(hgp(amp.to(dev), ph.to(dev), d.to(dev), complex_number=True), ref) < 1e-5
+    assert rel_err(hgp(amp.to(dev), ph.to(dev), d.to(dev)).cpu(), orc.holo_generator(hp, amp, ph, d)) < 1e-5
+    ref_s = orc.holo_generator(hp, amp, ph, 0.35, complex_number=True)       # Python-float distance
+    assert cplx_rel(hgp(amp.to(dev), ph.to(dev), 0.35, complex_number=True), ref_s) < 1e-5
+    amp2, ph2 = amp.repeat(1, 2, 1, 1) * torch.tensor([1.0, 0.5]).view(1, 2, 1, 1), ph.repeat(1, 2, 1, 1)
+    ref2 = orc.holo_generator(hp, amp2, ph2, d, complex_number=True)          # C = 2: d broadcast over channels
+    assert cplx_rel(hgp(amp2.to(dev), ph2.to(dev), d.to(dev), complex_number=True), ref2) < 1e-5

@@ -118,7 +118,12 @@ def main():
     args = ap.parse_args()
 
     from style_transfer_based_holographic_imaging_amd import ops, shard, synth
-    rank, world, local = shard.init_from_env("nccl")
+    # RCCL ("nccl") on the GPU node; HOLO_DIST_BACKEND=gloo + HOLO_SHARE_GPU=1 rehearse the multi-rank control flow
+    # with several ranks on ONE card (the one-GPU development box)
+    backend = os.environ.get("HOLO_DIST_BACKEND", "nccl")
+    rank, world, local = shard.init_from_env(backend)
+    if os.environ.get("HOLO_SHARE_GPU") == "1":
+        local = min(local, torch.cuda.device_count() - 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():

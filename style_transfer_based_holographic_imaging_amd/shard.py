@@ -31,7 +31,7 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(min(local, torch.cuda.device_count() - 1) if os.environ.get("HOLO_SHARE_GPU") == "1" else local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

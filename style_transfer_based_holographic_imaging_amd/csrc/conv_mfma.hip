@@ -31,11 +31,12 @@
 #ifndef HOLO_CONV_MINWAVES
 #define HOLO_CONV_MINWAVES 2   // minimum waves per SIMD the register allocator must allow
 #endif
+#ifndef HOLO_CONV_PRIVATE_B
+#define HOLO_CONV_PRIVATE_B 0   // 0: block-shared weight tile, one barrier per tap (default: measured faster);
+                                // 1: every wave DMAs its own weight rows, barrier only per chunk (-5 % fp32, -19 % bf16)
+#endif
 #ifndef HOLO_CONV_SETPRIO
 #define HOLO_CONV_SETPRIO 0
-#endif
-#ifndef HOLO_CONV_GLDS
-#define HOLO_CONV_GLDS 1   // 1: LDS-DMA staging (global_load_lds_dwordx4); 0: register staging
 #endif
 
 namespace holo {
@@ -74,7 +75,11 @@ struct ConvCfg {
     static constexpr int B_ROUNDS = (B_UNITS + THREADS - 1) / THREADS;
     static constexpr int A_BYTES = HR * HW * ROWB;
     static constexpr int B_BYTES = TN * ROWB;
-    static constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;
+    // wave-private weight tiles: each wave stages the 32*WT weight rows it consumes itself (two buffers)
+    static constexpr int BW_ROWS = 32 * WT;
+    static constexpr int BW_BYTES = BW_ROWS * ROWB;
+    static constexpr int BP_ROUNDS = BW_ROWS * UPR / 64;
+    static constexpr int LDS_BYTES = 2 * A_BYTES + (HOLO_CONV_PRIVATE_B ? WM * WN * 2 * BW_BYTES : 2 * B_BYTES);
     // A is re-staged every chunk; for CONVT every stage is a new chunk
 };
 
@@ -126,6 +131,24 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
         const int rx = reflect1(x0 - C::HALO + hx, W);
         a_src[r] = (ry * W + rx) * Cin + C::EPU * c;
     }
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+#if HOLO_CONV_PRIVATE_B
+    // Experiment (off by default): weight tile WAVE-PRIVATE — unit u = lane + 64*r of this wave's region holds
+    // (swizzled) unit u % UPR of the wave's weight row u / UPR.  Only the issuing wave reads it, so its own
+    // s_waitcnt vmcnt(0) is all the synchronisation the weights need and the block barrier remains only where the
+    // SHARED halo tile swaps (once per chunk instead of once per tap; the per-tap barrier held ~10 % of the
+    // wave-cycles in the PMC profile).  Price: waves that share output channels fetch the same rows twice and each
+    // lane issues twice the LDS-DMA instructions — measured 126.8 vs 133.8 TFLOP/s (fp32), 695 vs 860 (bf16).
+    int b_src[C::BP_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < C::BP_ROUNDS; ++r) {
+        const int u = lane + r * 64;
+        const int row = u / C::UPR, c = swz_unit<C::ROWB>(row, u % C::UPR);
+        b_src[r] = (wn * C::BW_ROWS + row) * KC + C::EPU * c;
+    }
+    const int b_region = 2 * C::A_BYTES + wave * 2 * C::BW_BYTES;   // byte offset of this wave's two weight buffers
+#else
     int b_src[C::B_ROUNDS];
 #pragma unroll
     for (int r = 0; r < C::B_ROUNDS; ++r) {
@@ -133,14 +156,14 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
         const int co = u / C::UPR, c = swz_unit<C::ROWB>(co, u % C::UPR);
         b_src[r] = co * KC + C::EPU * c;
     }
-#if HOLO_CONV_GLDS
-    // global_load_lds_dwordx4: no staging VGPRs, no ds_write; completion = s_waitcnt vmcnt(0) before the barrier
-    const int wave_base = (tid & ~63) * 16;   // byte offset of this wave's first unit within a round
+#endif
+    // global_load_lds_dwordx4: no staging VGPRs, no ds_write; completion = s_waitcnt vmcnt(0)
+    const int wave_base = (tid & ~63) * 16;   // byte offset of this wave's first unit within a block-wide round
     const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
 // Issued from inline asm on purpose: through the builtin, hipcc orders every later ds_read behind the
 // pending LDS write and drains vmcnt(0) before the first fragment read of the stage (seen in the ISA),
 // which serialises the DMA with the MFMAs.  The asm form is invisible to that pass; completion is our
-// own s_waitcnt vmcnt(0) right before the stage barrier.  M0 (LDS base of the DMA) is saved/restored.
+// own s_waitcnt vmcnt(0) at the end of the stage.  M0 (LDS base of the DMA) is saved/restored.
 #define HOLO_GLDS16(gsrc_, ldst_)                                                                          \
     {                                                                                                     \
         unsigned m0_keep;                                                                                 \
@@ -157,6 +180,13 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
             HOLO_GLDS16(ximg + a_src[r] + (chunk_) * KC,                                                 \
                         (buf_) * C::A_BYTES + r * C::THREADS * 16 + wave_base)                           \
     }
+#if HOLO_CONV_PRIVATE_B
+#define HOLO_LOAD_B(wsrc_, buf_)                                                                          \
+    {                                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < C::BP_ROUNDS; ++r)                                          \
+            HOLO_GLDS16((wsrc_) + b_src[r], b_region + (buf_) * C::BW_BYTES + r * 1024)                   \
+    }
+#else
 #define HOLO_LOAD_B(wsrc_, buf_)                                                                          \
     {                                                                                                     \
         _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                         \
@@ -164,49 +194,17 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
                 HOLO_GLDS16((wsrc_) + b_src[r], 2 * C::A_BYTES + (buf_) * C::B_BYTES + r * C::THREADS * 16 + wave_base) \
         }                                                                                                 \
     }
-#define HOLO_STORE_A(buf_)
-#define HOLO_STORE_B(buf_)
-#define HOLO_STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-    // register staging: global loads issued before the MFMAs of a stage, ds_write after them
-    float4 a_reg[C::A_ROUNDS], b_reg[C::B_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < C::A_ROUNDS; ++r) a_reg[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < C::B_ROUNDS; ++r) b_reg[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-#define HOLO_LOAD_A(chunk_, buf_)                                                                         \
-    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
-        if (tid + r * C::THREADS < C::A_UNITS)                                                            \
-            a_reg[r] = *reinterpret_cast<const float4*>(ximg + a_src[r] + (chunk_) * KC);                \
-    }
-#define HOLO_STORE_A(buf_)                                                                                \
-    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
-        if (tid + r * C::THREADS < C::A_UNITS)                                                            \
-            *reinterpret_cast<float4*>(lds_a + (buf_) * C::A_BYTES + (tid + r * C::THREADS) * 16) = a_reg[r]; \
-    }
-#define HOLO_LOAD_B(wsrc_, buf_)                                                                          \
-    {                                                                                                     \
-        _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                         \
-            if (tid + r * C::THREADS < C::B_UNITS) b_reg[r] = *reinterpret_cast<const float4*>((wsrc_) + b_src[r]); \
-        }                                                                                                 \
-    }
-#define HOLO_STORE_B(buf_)                                                                                \
-    _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                             \
-        if (tid + r * C::THREADS < C::B_UNITS)                                                            \
-            *reinterpret_cast<float4*>(lds_b + (buf_) * C::B_BYTES + (tid + r * C::THREADS) * 16) = b_reg[r]; \
-    }
-#define HOLO_STAGE_WAIT()
 #endif
+#define HOLO_STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
     // ---- per-lane MFMA operand coordinates -----------------------------------------------------------
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
     const int hsel = lane >> 5, li = lane & 31;
     const int lpx = (li & 1) | ((li >> 2) << 1);
     const int lpy = wm * (2 * WT) + ((li >> 1) & 1);  // + 2*mt
     int b_off[WT];
 #pragma unroll
-    for (int nt = 0; nt < WT; ++nt) b_off[nt] = swz<C::ROWB>(wn * (32 * WT) + nt * 32 + li, hsel);
+    for (int nt = 0; nt < WT; ++nt)
+        b_off[nt] = swz<C::ROWB>((HOLO_CONV_PRIVATE_B ? 0 : wn * (32 * WT)) + nt * 32 + li, hsel);
 
     // acc: the MFMA chain of the current 16-channel chunk (9 taps x 16 channels = 144 terms);
     // tot: running sum of the finished chunks.  One fp32 fmaf chain over all 9*Cin terms (up to 4608)
@@ -234,8 +232,6 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
     const size_t w_stage = (size_t)N * KC;
     HOLO_LOAD_A(0, 0)
     HOLO_LOAD_B(wsrc, 0)
-    HOLO_STORE_A(0)
-    HOLO_STORE_B(0)
     HOLO_STAGE_WAIT();
     __syncthreads();
 
@@ -253,7 +249,11 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
             if (tap == kLast && more_chunks) { HOLO_LOAD_A(chunk + 1, apar ^ 1) }
 
             const unsigned char* abuf = lds_a + apar * C::A_BYTES;
+#if HOLO_CONV_PRIVATE_B
+            const unsigned char* bbuf = smem + b_region + bpar * C::BW_BYTES;
+#else
             const unsigned char* bbuf = lds_b + bpar * C::B_BYTES;
+#endif
             const int dy = CONVT ? 0 : tap / 3, dx = CONVT ? 0 : tap % 3;   // constants after unrolling
             int a_off[WT];
 #pragma unroll
@@ -305,10 +305,8 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
 #pragma unroll
                     for (int nt = 0; nt < WT; ++nt) tot[mt][nt] += acc[mt][nt];
             }
-            if (has_next) { HOLO_STORE_B(bpar ^ 1) }
-            if (tap == kLast && more_chunks) { HOLO_STORE_A(apar ^ 1) }
-            HOLO_STAGE_WAIT();
-            __syncthreads();
+            HOLO_STAGE_WAIT();                                   // this wave's DMAs (next weights, its share of the next halo)
+            if (!HOLO_CONV_PRIVATE_B || tap == kLast) __syncthreads();   // shared data: everybody's DMAs have landed
             bpar ^= 1;
         }
         apar ^= 1;
@@ -374,9 +372,8 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
 }
 
 #undef HOLO_LOAD_A
-#undef HOLO_STORE_A
 #undef HOLO_LOAD_B
-#undef HOLO_STORE_B
+#undef HOLO_GLDS16
 #undef HOLO_STAGE_WAIT
 
 template <int WM, int WN, bool CONVT, int KC, typename T, int WT = 2>

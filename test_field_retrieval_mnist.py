@@ -26,30 +26,28 @@ import torch
 import torch.nn as nn
 
 
+# (flag, type, default) — names and defaults of the reference's argparse block (test_field_retrieval_mnist.py:39-62);
+# only --device differs (this implementation is HIP-only)
+REFERENCE_FLAGS = (
+    ("data_name", str, "MNIST"), ("decoder_root", str, "./models/MNIST"), ("vgg", str, "./models/vgg_normalised.pth"),
+    ("device", str, "cuda"), ("exp_name", str, "MNIST_test"), ("save_dir", str, "./output"), ("save_ext", str, ".png"),
+    ("img_size", int, 128), ("n_layer", int, 4), ("unknown_distance", int, 1),
+    ("wavelength", float, 532e-9), ("pixel_size", float, 1.5e-6), ("phase_normalize", float, 1.0),
+    ("distance_normalize", float, 1.0), ("distance_normalize_constant", float, 0.0),
+)
+
+
 def parse_args(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--data_name', type=str, default='MNIST')
-    parser.add_argument('--decoder_root', default='./models/MNIST', type=str)
-    parser.add_argument('--vgg', type=str, default='./models/vgg_normalised.pth')
-    parser.add_argument('--device', type=str, default='cuda')
-    parser.add_argument('--exp_name', type=str, default='MNIST_test')
-    parser.add_argument('--save_dir', default='./output')
-    parser.add_argument('--save_ext', default='.png')
-    parser.add_argument('--img_size', type=int, default=128)
-    parser.add_argument('--n_layer', type=int, default=4)
-    parser.add_argument('--unknown_distance', type=int, default=1)
-    parser.add_argument('--wavelength', type=float, default=532e-9)
-    parser.add_argument('--pixel_size', type=float, default=1.5e-6)
-    parser.add_argument('--phase_normalize', type=float, default=1.0)
-    parser.add_argument('--distance_normalize', type=float, default=1.0)
-    parser.add_argument('--distance_normalize_constant', type=float, default=0.0)
-    # additive
-    parser.add_argument('--synthetic-weights', type=int, default=None, metavar='SEED',
-                        help='use seeded He-normal weights when the trained files are absent')
-    parser.add_argument('--unwrap', choices=['auto', 'on', 'off'], default='auto')
-    parser.add_argument('--data_root', default='./test_data')
-    parser.add_argument('--no-images', action='store_true', help='skip the per-sample PNG mosaics')
-    return parser.parse_args(argv)
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for name, kind, default in REFERENCE_FLAGS:
+        ap.add_argument(f"--{name}", type=kind, default=default)
+    extra = ap.add_argument_group("additions of this implementation")
+    extra.add_argument("--synthetic-weights", type=int, default=None, metavar="SEED",
+                       help="use seeded He-normal weights when the trained files are absent")
+    extra.add_argument("--unwrap", choices=["auto", "on", "off"], default="auto")
+    extra.add_argument("--data_root", default="./test_data")
+    extra.add_argument("--no-images", action="store_true", help="skip the per-sample PNG mosaics")
+    return ap.parse_args(argv)
 
 
 def load_weights(args, device):

@@ -67,24 +67,19 @@ class Holo_Generator(nn.Module):
 
 class Back_prop(nn.Module):
     """utils/Forward_model.py:42-65 of the reference (never instantiated by its scripts): sqrt(hologram) propagated
-    on the UN-padded grid, returned as [abs, angle] or [re, im] stacked on the channel axis."""
+    on the UN-padded grid, returned as [abs, angle] ('amp_pha') or [re, im] stacked on the channel axis."""
+
+    _FIELDS = ("amplitude_normalize", "wavelength", "pixel_size", "distance_normalize", "distance_normalize_constant")
 
     def __init__(self, args):
-        super(Back_prop, self).__init__()
-        self.amplitude_normalize = args.amplitude_normalize
-        self.wavelength = args.wavelength
-        self.pixel_size = args.pixel_size
-        self.distance_normalize = args.distance_normalize
-        self.distance_normalize_constant = args.distance_normalize_constant
+        super().__init__()
+        for name in self._FIELDS:
+            setattr(self, name, getattr(args, name))
         self.input_type = args.Holo_G_input
 
     def forward(self, holo, d):
         from utils.Angular_Spectrum_Method import ASM
-        d = ((d + self.distance_normalize_constant) * self.distance_normalize) * 0.001
-        holo = torch.sqrt(holo)
-        o = ASM(holo, self.wavelength, d, self.pixel_size) * self.amplitude_normalize
-        if self.input_type == 'amp_pha':
-            r, i = torch.abs(o), torch.angle(o)
-        else:
-            r, i = torch.real(o), torch.imag(o)
-        return torch.cat([r, i], dim=1)
+        metres = (d + self.distance_normalize_constant) * self.distance_normalize * 0.001
+        field = ASM(torch.sqrt(holo), self.wavelength, metres, self.pixel_size) * self.amplitude_normalize
+        parts = (field.abs(), field.angle()) if self.input_type == 'amp_pha' else (field.real, field.imag)
+        return torch.cat(parts, dim=1)

@@ -5,12 +5,12 @@ import torch
 
 
 def field_retrieval(network, content, style_vector, alpha=1.0, unkonwn_distance=False):
+    """(amplitude, phase[, distance (B,1,1,1)]) — the reference's keyword is misspelt and kept as is."""
     assert (0.0 <= alpha <= 1.0)
-    if unkonwn_distance:
-        amplitude, phase, distance_content = network.field_retrieval(content, style_vector, alpha, unkonwn_distance)
-        return amplitude, phase, distance_content.view(-1, 1, 1, 1)
-    amplitude, phase = network.field_retrieval(content, style_vector, alpha)
-    return amplitude, phase
+    if not unkonwn_distance:
+        return network.field_retrieval(content, style_vector, alpha)
+    amplitude, phase, dist = network.field_retrieval(content, style_vector, alpha, unkonwn_distance)
+    return amplitude, phase, dist.view(-1, 1, 1, 1)
 
 
 def unwrap(x):
@@ -30,8 +30,3 @@ def unwrap(x):
             ph = ph.squeeze()
         out.append(torch.from_numpy(unwrap_phase(ph)).unsqueeze(0).unsqueeze(0))
     return torch.cat(out, dim=0)
-
-
-def center_crop(H, size):
-    batch, channel, Nh, Nw = H.size()
-    return H[:, :, (Nh - size) // 2:(Nh + size) // 2, (Nw - size) // 2:(Nw + size) // 2]

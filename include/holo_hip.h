@@ -133,6 +133,23 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 2-D phase unwrapping (utils/functions.py:44-59 `unwrap`, reached with unwrap=True from
+ * utils/Forward_model.py:30-31 and test_field_retrieval_mnist.py:126).  The reference loops over the
+ * images on the host and calls scikit-image's unwrap_phase (Herraez et al. 2002, reliability-sorted
+ * non-continuous path); this entry point builds the same minimum spanning tree of edge reliabilities
+ * on the device (Boruvka rounds) for all images at once.  Global multiple of 2 pi per image: the most
+ * frequent integer offset is 0.  Border pixels use the constant reliability 9999999 where the library
+ * adds rand(); ties are ordered by edge id (csrc/unwrap.hip, oracle/unwrap_oracle.py).
+ * ---------------------------------------------------------------------------------------- */
+/* bytes of 8-byte aligned scratch for holo_unwrap2d_f32 (24 per pixel) */
+size_t holo_unwrap2d_workspace_bytes(int batch, int h, int w);
+
+/* phase/out: `batch` images of h x w fp32, row-major, in_stride / out_stride floats apart (>= h*w);
+ * out may not alias phase.  h*w <= 2^24, batch <= 65535. */
+int holo_unwrap2d_f32(const float* phase, long in_stride, float* out, long out_stride, int batch, int h, int w,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * bf16 variants (BASELINE config 3: "bf16 convs / fp32 FFT").  Same layouts and semantics as the _f32 entry
  * points; activations and packed weights are bf16 (uint16_t storage), bias, statistics, accumulation
  * (v_mfma_f32_32x32x16_bf16) and the last layer's amplitude/phase planes stay fp32.  Cin % 32 == 0.

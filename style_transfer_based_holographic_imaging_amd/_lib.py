@@ -43,6 +43,8 @@ SIGNATURES = {
     "holo_linear1_sigmoid_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "holo_asm_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "holo_asm_propagate": (_i, [_p, _p, _i, _l, _l, _p, _p, _i, _l, _l, _p, _i, _i, _i, _i, _d, _d, _f, _p, _z, _p]),
+    "holo_unwrap2d_workspace_bytes": (_z, [_i, _i, _i]),
+    "holo_unwrap2d_f32": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _z, _p]),
     "holo_pack_conv3x3_weight_bf16": (_i, [_p, _p, _i, _i, _p]),
     "holo_pack_convt2x2_weight_bf16": (_i, [_p, _p, _i, _i, _p]),
     "holo_conv_first_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -415,3 +415,29 @@ def asm_propagate(in0, in1, phase_c, s, zero_padding, wavelength, pixel_size, ph
             float(wavelength), float(pixel_size), float(phase_scale), ws.data_ptr(), ws_bytes, _stream()),
                 nbytes=(24.0 + 56.0 * n_dist) * plane * nf, fresh=True)
     return out0, out1
+
+
+_UNWRAP_WS_BUDGET = 4 << 30
+
+
+def unwrap2d(phase: torch.Tensor) -> torch.Tensor:
+    """Per-image 2-D phase unwrapping of (B,1,H,W) / (B,H,W) / (H,W) float32 phase maps on the device
+    (utils/functions.py:44-59).  Returns a new (B,1,H,W) float32 tensor, like the reference's wrapper."""
+    _req(phase)
+    h, w = phase.shape[-2:]
+    x = phase.reshape(-1, h, w)
+    x = x if x.dtype == torch.float32 else x.float()
+    b = x.shape[0]
+    if not (x.stride(2) == 1 and x.stride(1) == w and (b == 1 or x.stride(0) >= h * w)):
+        x = x.contiguous()
+    st = x.stride(0) if b > 1 else h * w     # batch-strided views such as field[:, 1:] need no copy
+    out = torch.empty((b, 1, h, w), dtype=torch.float32, device=x.device)
+    group = max(1, min(b, _UNWRAP_WS_BUDGET // (24 * h * w), 65535))
+    ws_bytes = lib.holo_unwrap2d_workspace_bytes(group, h, w)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    for i0 in range(0, b, group):
+        nb = min(group, b - i0)
+        _launch("holo_unwrap2d_f32", lambda: lib.holo_unwrap2d_f32(
+            x.data_ptr() + i0 * st * 4, st, out.data_ptr() + i0 * h * w * 4, h * w, nb, h, w,
+            ws.data_ptr(), ws_bytes, _stream()), nbytes=8.0 * h * w * nb, fresh=True)
+    return out

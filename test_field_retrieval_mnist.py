@@ -12,8 +12,8 @@ Differences, all additive:
     under --decoder_root / --vgg are absent, `--synthetic-weights SEED` runs the identical pipeline on
     seeded He-normal weights (numbers are then meaningless as reconstructions, but every kernel runs).
   * tensors are loaded with map_location (the bundled .pt files carry a cuda:0 storage tag).
-  * phase unwrapping needs scikit-image exactly as in the reference; `--unwrap auto` (default) uses it
-    when importable and otherwise leaves the focused phase wrapped, saying so.
+  * the focused phase is unwrapped on the GPU (`holo_unwrap2d_f32`) instead of a host loop over scikit-image;
+    `--unwrap off` keeps it wrapped.
 """
 import argparse
 import copy
@@ -44,7 +44,7 @@ def parse_args(argv=None):
     extra = ap.add_argument_group("additions of this implementation")
     extra.add_argument("--synthetic-weights", type=int, default=None, metavar="SEED",
                        help="use seeded He-normal weights when the trained files are absent")
-    extra.add_argument("--unwrap", choices=["auto", "on", "off"], default="auto")
+    extra.add_argument("--unwrap", choices=["on", "off"], default="on")
     extra.add_argument("--data_root", default="./test_data")
     extra.add_argument("--no-images", action="store_true", help="skip the per-sample PNG mosaics")
     return ap.parse_args(argv)
@@ -110,12 +110,6 @@ def main(argv=None):
     style_vector = torch.load(args.style_path, map_location='cpu').to(device).float()
 
     use_unwrap = args.unwrap == 'on'
-    if args.unwrap == 'auto':
-        try:
-            import skimage.restoration  # noqa: F401
-            use_unwrap = True
-        except ImportError:
-            print("[note] scikit-image is not installed: the focused phase stays wrapped (--unwrap off)")
 
     psnr_list, mae_list, distance_list = [], [], []
     vis_idx = 0
@@ -133,7 +127,6 @@ def main(argv=None):
             amp_foc, ph_foc = model_forward(amp_field, ph_field * args.phase_normalize,
                                             -distance_style - 2 * args.distance_normalize_constant,
                                             return_field=True, unwrap=use_unwrap)
-            ph_foc = ph_foc.to(device)
             gt_phase -= torch.mean(gt_phase, dim=(-2, -1), keepdim=True).expand_as(gt_phase)
             ph_field -= torch.mean(ph_field, dim=(-2, -1), keepdim=True).expand_as(amp_field)
             ph_foc -= torch.mean(ph_foc, dim=(-2, -1), keepdim=True).expand_as(amp_foc)

@@ -14,15 +14,21 @@ def field_retrieval(network, content, style_vector, alpha=1.0, unkonwn_distance=
 
 
 def unwrap(x):
-    """Per-image 2-D phase unwrapping on the host with scikit-image, as the reference does.  The
-    dependency is third-party native code the reference neither vendors nor pins; where it is not
-    installed this raises instead of inventing a result (parity for unwrap is unpinned)."""
+    """Per-image 2-D phase unwrapping, (B,1,H,W) in and out.
+
+    Device tensors: ``holo_unwrap2d_f32`` — the reliability-ordered spanning tree of the published algorithm
+    behind scikit-image's ``unwrap_phase``, built on the GPU for the whole batch (csrc/unwrap.hip); the result
+    stays on the device in float32, where the reference returns a host tensor.  Host tensors take the
+    reference's own route through scikit-image and raise when it is not installed."""
+    if x.is_cuda:
+        from style_transfer_based_holographic_imaging_amd import ops
+        return ops.unwrap2d(x.detach())
     try:
         from skimage.restoration import unwrap_phase
     except ImportError as e:
-        raise ImportError("utils.functions.unwrap needs scikit-image (skimage.restoration.unwrap_phase), "
-                          "which is not installed; call Holo_Generator(..., unwrap=False)") from e
-    x = x.cpu().detach().numpy()
+        raise ImportError("utils.functions.unwrap on a host tensor needs scikit-image "
+                          "(skimage.restoration.unwrap_phase), which is not installed") from e
+    x = x.detach().numpy()
     out = []
     for i in range(x.shape[0]):
         ph = x[i]

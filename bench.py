@@ -246,6 +246,18 @@ def main():
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(summ.items())}
             out["conv_stack_tflops_overall"] = round(FLOP_PER_PIXEL * s * s * b * args.steps / 1e12 /
                                                      (sum(v["ms"] for k, v in summ.items() if "conv" in k) * 1e-3), 2)
+        if args.distances == 1:
+            # the step after the metric's path (test_field_retrieval_mnist.py:126 unwrap=True): timed on its own,
+            # outside the holograms/s region, which SURVEY.md §8d defines pre-unwrap
+            from utils.functions import unwrap
+            p_f = step()[4]
+            unwrap(p_f)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                unwrap(p_f)
+            torch.cuda.synchronize()
+            out["unwrap_ms_per_batch"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(s, sds, style_cpu, args.cpu_sample, seed)
         print(json.dumps(out), flush=True)

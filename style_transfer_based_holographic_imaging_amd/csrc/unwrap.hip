@@ -14,11 +14,16 @@
 //   unwrap_boruvka_kernel       one persistent 1024-thread block per image:
 //        node[x] = (group root, offset of x relative to that root) packed in one 64-bit word, so that any
 //        single load sees a consistent pair and in-place pointer jumping needs no double buffering;
-//        round:  edge sweep   — 64-bit atomicMin of (round tag | weight bits | edge id) into both groups' slots
+//        round:  edge sweep   — every pixel takes the lightest of its edges that leave its group; a wave folds
+//                               runs of lanes with the same root (segmented min-scan) and the last lane of a run
+//                               issues one 64-bit atomic min of (round tag | weight bits | edge id) on the
+//                               group's slot; round 0 (every pixel alone) needs no atomics at all
 //                hook sweep   — each root follows its chosen edge; a mutual pair keeps the lower root
 //                jump sweeps  — node[x] <- (parent(parent), off + off(parent)) until flat
-//        the round tag (31 - round) in the top bits makes newer keys smaller than any stale one: no resets;
+//        the round tag (30 - round) in the top bits makes newer keys smaller than any stale one: no resets;
 //        afterwards offsets are re-based so the most frequent one is 0 and value + 2 pi k is stored.
+//        The sweeps are bound by one CU's L2 bandwidth/latency: every stage issues all its loads for several
+//        pixels unconditionally (clamped indices) before the first use.
 //
 // Total order of edges = (float32(rel1 + rel2), edge id), edge id = 2*pixel + (0 right | 1 down); border
 // pixels take the constant 9999999 (scikit-image adds rand() there).  oracle/unwrap_oracle.py restates the
@@ -39,11 +44,20 @@ constexpr int kHistBins = 1024;
 constexpr int kMaxRounds = 30;
 constexpr int kMaxJumps = 64;
 
+// One image is owned by one work-group, so every shared access is a relaxed atomic at WORK-GROUP scope (agent scope
+// would force each load past the XCD's L2 to stay coherent with the other seven, for nothing).
 __device__ __forceinline__ u64 ld64(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void st64(u64* p, u64 v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#ifndef HOLO_UNWRAP_SLOT_SCOPE
+#define HOLO_UNWRAP_SLOT_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+__device__ __forceinline__ u64 ld_slot(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, HOLO_UNWRAP_SLOT_SCOPE); }
+__device__ __forceinline__ void min64(u64* p, u64 v) {
+    __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, HOLO_UNWRAP_SLOT_SCOPE);
 }
 __device__ __forceinline__ u64 pack_node(unsigned parent, int off) { return ((u64)parent << 32) | (unsigned)off; }
 __device__ __forceinline__ unsigned node_parent(u64 n) { return (unsigned)(n >> 32); }
@@ -92,8 +106,12 @@ __global__ __launch_bounds__(256) void unwrap_weights_kernel(const double* __res
     reinterpret_cast<float2*>(wgt)[(size_t)img * n + x] = w;
 }
 
-__device__ __forceinline__ void offer_edge(u64* best, unsigned root, u64 key) {
-    if (key < ld64(best + root)) atomicMin(best + root, key);
+// The sweeps below are bound by L2 latency (every load is a dependent, coherent access), so each thread keeps
+// several independent pixels in flight: all loads of a stage are issued before the first result is used.
+constexpr int kBatchEdge = 4, kBatchHook = 4, kBatchJump = 8;  // sized to stay inside 128 VGPRs (1024 threads)
+
+__device__ __forceinline__ u64 edge_key(u64 tag, float weight, unsigned eid) {
+    return tag | ((u64)__float_as_uint(weight) << kEidBits) | (u64)eid;
 }
 
 __global__ __launch_bounds__(kUnwrapThreads) void unwrap_boruvka_kernel(const float* __restrict__ phase, long in_stride,
@@ -110,80 +128,201 @@ __global__ __launch_bounds__(kUnwrapThreads) void unwrap_boruvka_kernel(const fl
     u64* __restrict__ best = best_all + (size_t)img * n;
     const float2* __restrict__ wgt = reinterpret_cast<const float2*>(wgt_all) + (size_t)img * n;
     const float* __restrict__ ph = phase + (size_t)img * in_stride;
-
-    for (int x = tid; x < n; x += kUnwrapThreads) {
-        st64(node + x, pack_node((unsigned)x, 0));
-        st64(best + x, ~0ull);
-    }
-    __syncthreads();
+    constexpr u64 kNoKey = ~0ull;
 
     // a grid of n pixels needs at most ceil(log2 n) <= 24 rounds; both loops are capped so the block always exits
+    int n_rounds = 0, n_jumps = 0;
+    long long t_edge = 0, t_hook = 0, t_jump = 0, t0 = wall_clock64(), t1;
     for (int round = 0; round < kMaxRounds; ++round) {
         const u64 tag = (u64)(kMaxRounds - round) << kTagShift;  // 1..30: never the 31 of an untouched slot
-        // ---- edge sweep: every group learns its lightest outgoing edge
         int any = 0;
-        for (int x = tid; x < n; x += kUnwrapThreads) {
-            const int yy = x / W, xx = x - yy * W;
-            const unsigned rx = node_parent(ld64(node + x));
-            const float2 w = wgt[x];
-            if (xx + 1 < W) {
-                const unsigned ry = node_parent(ld64(node + x + 1));
-                if (ry != rx) {
-                    const u64 key = tag | ((u64)__float_as_uint(w.x) << kEidBits) | (u64)(2 * x);
-                    offer_edge(best, rx, key);
-                    offer_edge(best, ry, key);
-                    any = 1;
+        if (round == 0) {
+            // ---- every pixel is its own group: its lightest incident edge needs no atomics
+            for (int base = tid; base < n; base += kUnwrapThreads * kBatchEdge) {
+                float2 w[kBatchEdge];
+                float wl[kBatchEdge], wu[kBatchEdge];
+#pragma unroll
+                for (int i = 0; i < kBatchEdge; ++i) {
+                    // loads are unconditional on clamped indices: a predicated load becomes a branch + wait
+                    const int x = min(base + i * kUnwrapThreads, n - 1);
+                    w[i] = wgt[x];
+                    wl[i] = wgt[max(x - 1, 0)].x;
+                    wu[i] = wgt[max(x - W, 0)].y;
+                }
+#pragma unroll
+                for (int i = 0; i < kBatchEdge; ++i) {
+                    const int x = base + i * kUnwrapThreads;
+                    if (x >= n) continue;
+                    const int xx = x % W;
+                    u64 k = kNoKey;
+                    if (xx + 1 < W) k = min(k, edge_key(tag, w[i].x, 2u * x));
+                    if (x + W < n) k = min(k, edge_key(tag, w[i].y, 2u * x + 1));
+                    if (xx > 0) k = min(k, edge_key(tag, wl[i], 2u * (x - 1)));
+                    if (x >= W) k = min(k, edge_key(tag, wu[i], 2u * (x - W) + 1));
+                    st64(node + x, pack_node((unsigned)x, 0));
+                    st64(best + x, k);
+                    any |= k != kNoKey;
                 }
             }
-            if (yy + 1 < H) {
-                const unsigned ry = node_parent(ld64(node + x + W));
-                if (ry != rx) {
-                    const u64 key = tag | ((u64)__float_as_uint(w.y) << kEidBits) | (u64)(2 * x + 1);
-                    offer_edge(best, rx, key);
-                    offer_edge(best, ry, key);
-                    any = 1;
+        } else {
+            // ---- edge sweep: every pixel offers the lightest of its (up to four) edges that leave its group.  Lanes
+            // are consecutive pixels of a row and groups are contiguous blobs, so a wave first folds runs of lanes
+            // with the same root (segmented min-scan) and only the last lane of a run touches the group's slot.
+            const int lane = tid & 63;
+            for (int b0 = 0; b0 < n; b0 += kUnwrapThreads * kBatchEdge) {  // wave-uniform trip count (shuffles below)
+                const int base = b0 + tid;
+                unsigned rx[kBatchEdge];
+                u64 key[kBatchEdge], nx[kBatchEdge], nr[kBatchEdge], nd[kBatchEdge], nl[kBatchEdge], nu[kBatchEdge];
+                float2 w[kBatchEdge];
+                float wl[kBatchEdge], wu[kBatchEdge];
+                // unconditional loads on clamped indices, all issued before the first use (a missing neighbour reads
+                // the pixel itself: same root, no edge)
+#pragma unroll
+                for (int i = 0; i < kBatchEdge; ++i) {
+                    const int xc = min(base + i * kUnwrapThreads, n - 1), xx = xc % W;
+                    const int il = xx > 0 ? xc - 1 : xc, iu = xc >= W ? xc - W : xc;
+                    nx[i] = ld64(node + xc);
+                    nr[i] = ld64(node + (xx + 1 < W ? xc + 1 : xc));
+                    nd[i] = ld64(node + (xc + W < n ? xc + W : xc));
+                    nl[i] = ld64(node + il);
+                    nu[i] = ld64(node + iu);
+                    w[i] = wgt[xc];
+                    wl[i] = wgt[il].x;
+                    wu[i] = wgt[iu].y;
                 }
+#pragma unroll
+                for (int i = 0; i < kBatchEdge; ++i) {
+                    const int x = base + i * kUnwrapThreads;
+                    const bool ok = x < n;
+                    const int xc = min(x, n - 1);
+                    const unsigned r = node_parent(nx[i]);
+                    u64 k = kNoKey;
+                    if (node_parent(nr[i]) != r) k = min(k, edge_key(tag, w[i].x, 2u * xc));
+                    if (node_parent(nd[i]) != r) k = min(k, edge_key(tag, w[i].y, 2u * xc + 1));
+                    if (node_parent(nl[i]) != r) k = min(k, edge_key(tag, wl[i], 2u * (xc - 1)));
+                    if (node_parent(nu[i]) != r) k = min(k, edge_key(tag, wu[i], 2u * (xc - W) + 1));
+                    rx[i] = ok ? r : 0xffffffffu - (unsigned)lane;  // padding lanes: runs of their own, no key
+                    key[i] = ok ? k : kNoKey;
+                }
+                u64 cur[kBatchEdge];
+                bool tail[kBatchEdge];
+#pragma unroll
+                for (int i = 0; i < kBatchEdge; ++i) {
+                    u64 k = key[i];
+                    const unsigned r = rx[i];
+                    // shuffles are executed by every lane (no short-circuit: a skipped lane would read as zero)
+                    const unsigned r_below = __shfl_up(r, 1), r_above = __shfl_down(r, 1);
+                    int sealed = (lane == 0) | (r_below != r);  // a run starts here: nothing further down joins
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const u64 k_dn = __shfl_up(k, d);
+                        const int s_dn = __shfl_up(sealed, d);
+                        if (lane >= d && !sealed) {
+                            k = min(k, k_dn);
+                            sealed = s_dn;
+                        }
+                    }
+                    tail[i] = ((lane == 63) | (r_above != r)) & (k != kNoKey);
+                    key[i] = k;
+                    // current slot contents: an offer that cannot win skips the atomic
+                    cur[i] = ld_slot(best + (tail[i] ? r : 0u));
+                    any |= tail[i];
+                }
+#pragma unroll
+                for (int i = 0; i < kBatchEdge; ++i)
+                    if (tail[i] && key[i] < cur[i]) min64(best + rx[i], key[i]);
             }
         }
         if (!__syncthreads_or(any)) break;  // one group left
+        ++n_rounds;
+        t1 = wall_clock64(); t_edge += t1 - t0; t0 = t1;
         // ---- hook sweep: roots follow their edge (writes touch root entries only)
-        for (int x = tid; x < n; x += kUnwrapThreads) {
-            const u64 nx = ld64(node + x);
-            if (node_parent(nx) != (unsigned)x) continue;
-            const u64 b = ld64(best + x);
-            if ((b >> kTagShift) != (tag >> kTagShift)) continue;
-            const unsigned eid = (unsigned)(b & ((1ull << kEidBits) - 1));
-            const int u = (int)(eid >> 1);
-            const int v = u + ((eid & 1) ? W : 1);
-            const u64 nu = ld64(node + u), nv = ld64(node + v);
-            const bool mine_is_u = node_parent(nu) == (unsigned)x;
-            const u64 na = mine_is_u ? nu : nv;   // endpoint inside this group
-            const u64 nb = mine_is_u ? nv : nu;   // endpoint in the other group
-            const unsigned other = node_parent(nb);
-            if (other == (unsigned)x) continue;   // the partner of a mutual pair has already hooked onto this root
-            if (ld64(best + other) == b && (unsigned)x < other) continue;  // mutual pair: the lower root stays
-            // offsets k with unwrapped = value + 2 pi k:  k[a] - k[b] = +1 if value[b] - value[a] > pi, -1 if < -pi
-            const double va = ph[mine_is_u ? u : v], vb = ph[mine_is_u ? v : u];
-            const double d = vb - va;
-            const int jump = d > kPi ? 1 : (d < -kPi ? -1 : 0);
-            st64(node + x, pack_node(other, node_off(nb) - node_off(na) + jump));
+        for (int base = tid; base < n; base += kUnwrapThreads * kBatchHook) {
+            u64 b[kBatchHook], nu[kBatchHook], nv[kBatchHook];
+            int eu[kBatchHook], ev[kBatchHook];
+            bool live[kBatchHook];
+#pragma unroll
+            for (int i = 0; i < kBatchHook; ++i) {
+                const int x = base + i * kUnwrapThreads;
+                const int xc = min(x, n - 1);
+                const u64 nx = ld64(node + xc);
+                b[i] = ld_slot(best + xc);
+                live[i] = x < n && node_parent(nx) == (unsigned)x;
+            }
+#pragma unroll
+            for (int i = 0; i < kBatchHook; ++i) {
+                live[i] = live[i] && (b[i] >> kTagShift) == (tag >> kTagShift);
+                const unsigned eid = (unsigned)(b[i] & ((1ull << kEidBits) - 1));
+                eu[i] = live[i] ? (int)(eid >> 1) : 0;  // dead lanes read pixel 0 and discard it
+                ev[i] = live[i] ? eu[i] + ((eid & 1) ? W : 1) : 0;
+                nu[i] = ld64(node + eu[i]);
+                nv[i] = ld64(node + ev[i]);
+            }
+            u64 bo[kBatchHook];
+            float pu[kBatchHook], pv[kBatchHook];
+#pragma unroll
+            for (int i = 0; i < kBatchHook; ++i) {
+                const unsigned x = base + i * kUnwrapThreads;
+                const bool mine_is_u = node_parent(nu[i]) == x;
+                const unsigned other = node_parent(mine_is_u ? nv[i] : nu[i]);
+                live[i] = live[i] && other != x;  // else: the partner of a mutual pair has already hooked onto this root
+                bo[i] = ld_slot(best + (live[i] ? other : 0u));
+                pu[i] = ph[eu[i]];
+                pv[i] = ph[ev[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < kBatchHook; ++i) {
+                const unsigned x = base + i * kUnwrapThreads;
+                if (!live[i]) continue;
+                const bool mine_is_u = node_parent(nu[i]) == x;
+                const u64 na = mine_is_u ? nu[i] : nv[i];  // endpoint inside this group
+                const u64 nb = mine_is_u ? nv[i] : nu[i];  // endpoint in the other group
+                const unsigned other = node_parent(nb);
+                if (bo[i] == b[i] && x < other) continue;  // mutual pair: the lower root stays
+                // offsets k with unwrapped = value + 2 pi k:  k[a] - k[b] = +1 if value[b] - value[a] > pi, -1 if < -pi
+                const double d = mine_is_u ? (double)pv[i] - (double)pu[i] : (double)pu[i] - (double)pv[i];
+                const int jump = d > kPi ? 1 : (d < -kPi ? -1 : 0);
+                st64(node + x, pack_node(other, node_off(nb) - node_off(na) + jump));
+            }
         }
         __syncthreads();
+        t1 = wall_clock64(); t_hook += t1 - t0; t0 = t1;
         // ---- pointer jumping with offsets until every pixel points at its root
         for (int it = 0; it < kMaxJumps; ++it) {
             int changed = 0;
-            for (int x = tid; x < n; x += kUnwrapThreads) {
-                const u64 nx = ld64(node + x);
-                const unsigned p = node_parent(nx);
-                if (p == (unsigned)x) continue;
-                const u64 np = ld64(node + p);
-                const unsigned pp = node_parent(np);
-                if (pp == p) continue;
-                st64(node + x, pack_node(pp, node_off(nx) + node_off(np)));
-                changed = 1;
+            for (int base = tid; base < n; base += kUnwrapThreads * kBatchJump) {
+                u64 nx[kBatchJump], np[kBatchJump];
+#pragma unroll
+                for (int i = 0; i < kBatchJump; ++i) {
+                    const int x = base + i * kUnwrapThreads;
+                    nx[i] = ld64(node + min(x, n - 1));
+                    if (x >= n) nx[i] = pack_node((unsigned)x, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < kBatchJump; ++i) {
+                    const unsigned x = base + i * kUnwrapThreads;
+                    const unsigned p = node_parent(nx[i]);
+                    np[i] = ld64(node + (x < (unsigned)n ? p : 0u));
+                    if (p == x) np[i] = nx[i];
+                }
+#pragma unroll
+                for (int i = 0; i < kBatchJump; ++i) {
+                    const unsigned p = node_parent(nx[i]), pp = node_parent(np[i]);
+                    if (pp == p) continue;  // covers roots (np = nx) and pixels already pointing at a root
+                    st64(node + base + i * kUnwrapThreads, pack_node(pp, node_off(nx[i]) + node_off(np[i])));
+                    changed = 1;
+                }
             }
+            ++n_jumps;
             if (!__syncthreads_or(changed)) break;
         }
+        t1 = wall_clock64(); t_jump += t1 - t0; t0 = t1;
+    }
+    // rounds and pointer-jumping sweeps it took, for profiling (the edge slots are dead from here on)
+    if (tid == 0 && n >= 2) {
+        best[0] = (u64)n_rounds;
+        best[1] = (u64)n_jumps;
+        best[2] = (u64)t_edge; best[3] = (u64)t_hook; best[4] = (u64)t_jump;
     }
 
     // ---- re-base: the most frequent offset becomes 0 (lowest offset wins a tie)

@@ -163,10 +163,18 @@ def main():
             else:
                 a_f, p_f = model_forward(amp, p * 1.0, -d_style, return_field=True, unwrap=False)
             if world > 1 and args.distances == 1:
-                shard.gather_to_root(shard.pack_outputs(amp, p, a_f, p_f, d))
+                # the step's one exchange: started here, waited for one step later, so it rides under the next
+                # step's kernels; sync() drains the last one inside the timed region
+                pending.append(shard.gather_to_root(shard.pack_outputs(amp, p, a_f, p_f, d), async_op=True))
+                if len(pending) > 1:
+                    pending.pop(0).wait()
         return amp, p, d, a_f, p_f
 
+    pending = []
+
     def sync():
+        while pending:
+            pending.pop(0).wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -246,9 +254,10 @@ def main():
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(summ.items())}
             out["conv_stack_tflops_overall"] = round(FLOP_PER_PIXEL * s * s * b * args.steps / 1e12 /
                                                      (sum(v["ms"] for k, v in summ.items() if "conv" in k) * 1e-3), 2)
-        if args.distances == 1:
+        if world == 1 and args.distances == 1:
             # the step after the metric's path (test_field_retrieval_mnist.py:126 unwrap=True): timed on its own,
-            # outside the holograms/s region, which SURVEY.md §8d defines pre-unwrap
+            # outside the holograms/s region, which SURVEY.md §8d defines pre-unwrap.  Single rank only: nothing
+            # after the timed region may issue a collective the other ranks do not join.
             from utils.functions import unwrap
             p_f = step()[4]
             unwrap(p_f)

@@ -50,12 +50,30 @@ def unpack_outputs(packed, s):
     return (*planes, packed[:, 4 * n:].reshape(b, 1, 1, 1))
 
 
-def gather_to_root(packed: torch.Tensor, counts: list[int] | None = None, dst: int = 0):
+class PendingGather:
+    """A gather in flight.  ``wait()`` makes the current stream wait for it and returns what ``gather_to_root``
+    returns.  Holding the handle keeps the send/receive buffers alive, so the next step's kernels can be enqueued
+    before the collective has finished: the exchange rides under the following step's compute."""
+
+    def __init__(self, work, out, counts, is_root, keep):
+        self._work, self._out, self._counts, self._is_root, self._keep = work, out, counts, is_root, keep
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        if not self._is_root or self._out is None:
+            return None
+        return self._out if self._counts is None else _trim(self._out, self._counts)
+
+
+def gather_to_root(packed: torch.Tensor, counts: list[int] | None = None, dst: int = 0, async_op: bool = False):
     """One gather of every rank's packed block to ``dst``.  Returns the concatenated (N_total, F)
-    tensor on ``dst`` and None elsewhere.  ``counts`` (rows per rank) allows ragged shards: blocks
-    are padded to the largest and trimmed on the root."""
+    tensor on ``dst`` and None elsewhere (``async_op``: a ``PendingGather`` whose ``wait()`` returns that).
+    ``counts`` (rows per rank) allows ragged shards: blocks are padded to the largest and trimmed on the root."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return packed
+        return PendingGather(None, packed, None, True, None) if async_op else packed
     world, rank = dist.get_world_size(), dist.get_rank()
     counts = counts or [packed.shape[0]] * world
     rows = max(counts)
@@ -63,21 +81,24 @@ def gather_to_root(packed: torch.Tensor, counts: list[int] | None = None, dst: i
         pad = torch.zeros((rows - packed.shape[0], packed.shape[1]), dtype=packed.dtype, device=packed.device)
         packed = torch.cat([packed, pad], 0)
     global _GATHER_UNSUPPORTED
+    work, out = None, None
     if not _GATHER_UNSUPPORTED:
         try:
             if rank == dst:
                 out = torch.empty((world, rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
-                dist.gather(packed, list(out.unbind(0)), dst=dst)
-                return out[0] if world == 1 else _trim(out, counts)
-            dist.gather(packed, None, dst=dst)
-            return None
+                work = dist.gather(packed, list(out.unbind(0)), dst=dst, async_op=True)
+            else:
+                work = dist.gather(packed, None, dst=dst, async_op=True)
         except (RuntimeError, NotImplementedError) as e:   # a backend without gather: every rank sees the same error
             _GATHER_UNSUPPORTED = True
+            work, out = None, None
             if rank == dst:
                 print(f"[shard] dist.gather unavailable ({type(e).__name__}); using all_gather_into_tensor", flush=True)
-    out = torch.empty((world, rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed)
-    return _trim(out, counts) if rank == dst else None
+    if work is None:
+        out = torch.empty((world, rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        work = dist.all_gather_into_tensor(out, packed, async_op=True)
+    pending = PendingGather(work, out, counts, rank == dst, packed)
+    return pending if async_op else pending.wait()
 
 
 _GATHER_UNSUPPORTED = False

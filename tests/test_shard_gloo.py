@@ -39,7 +39,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n_total, size, out_path):
+def _worker(rank, world, port, n_total, size, out_path, pipelined=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from style_transfer_based_holographic_imaging_amd import shard
@@ -52,7 +52,16 @@ def _worker(rank, world, port, n_total, size, out_path):
     planes = [idx * 1000 + base + k for k in range(4)]
     packed = shard.pack_outputs(*planes, idx * 0.001)
     counts = [shard.shard_bounds(n_total, world, q)[1] - shard.shard_bounds(n_total, world, q)[0] for q in range(world)]
-    gathered = shard.gather_to_root(packed, counts)
+    if pipelined:
+        # bench.py's pattern: the gather of step k is waited for after step k+1 has been issued
+        first = shard.gather_to_root(packed, counts, async_op=True)
+        second = shard.gather_to_root(packed + 1.0, counts, async_op=True)
+        gathered, later = first.wait(), second.wait()
+        assert (later is None) == (rank != 0)
+        if rank == 0:
+            assert torch.equal(later, gathered + 1.0)
+    else:
+        gathered = shard.gather_to_root(packed, counts)
     if rank == 0:
         torch.save(gathered, out_path)
     else:
@@ -61,12 +70,13 @@ def _worker(rank, world, port, n_total, size, out_path):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("n_total", [8, 7])       # even and ragged shards
-def test_two_rank_gather(tmp_path, n_total):
+def test_two_rank_gather(tmp_path, n_total, pipelined):
     from style_transfer_based_holographic_imaging_amd import shard
     world, size = 2, 4
     out_path = str(tmp_path / "gathered.pt")
-    mp.spawn(_worker, args=(world, _free_port(), n_total, size, out_path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_total, size, out_path, pipelined), nprocs=world, join=True)
     g = torch.load(out_path)
     assert g.shape == (n_total, 4 * size * size + 1)
     amp, ph, a_f, p_f, d = shard.unpack_outputs(g, size)

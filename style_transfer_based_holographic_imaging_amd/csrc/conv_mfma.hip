@@ -53,17 +53,19 @@ constexpr int kPW = 16;  // patch width in pixels
 // T = float (exact fp32 MFMA, v_mfma_f32_32x32x2_f32) or bf16_t (v_mfma_f32_32x32x16_bf16, fp32 accumulate; BASELINE
 // config 3 "bf16 convs").  With 64-byte rows (16 fp32 / 32 bf16 channels) the staging plan, the swizzle and the
 // fragment reads are byte-for-byte the same for both: a lane's 16-byte read is 4 fp32 k-steps or one bf16 MFMA.
-template <int WM, int WN, bool CONVT, int KC, typename T, int WT = 2>
+template <int WM, int WN, bool CONVT, int KC, typename T, int WTM = 2, int WTN = WTM>
 struct ConvCfg {
     static constexpr int ES = (int)sizeof(T);
     static constexpr int EPU = 16 / ES;        // elements per 16-byte unit
     static constexpr int UPR = KC * ES / 16;   // 16-byte units per LDS row
     static constexpr int ROWB = KC * ES;       // bytes per LDS row
     static_assert(ROWB == 64 || ROWB == 128, "LDS rows are 64 or 128 bytes");
-    // WT = MFMA tiles per wave in each of M and N: 2 (wave tile 64 px x 64 co) or 1 (32 x 32, for grids that would
-    // otherwise underfill the chip: 4x the blocks per layer)
-    static constexpr int PR = WM * 2 * WT;  // patch rows
-    static constexpr int TN = WN * 32 * WT;
+    // WTM x WTN = MFMA tiles per wave along pixels / output channels: 2x2 (wave tile 64 px x 64 co), 1x1 (32 x 32,
+    // for grids that would otherwise underfill the chip: 4x the blocks per layer) or 4x2 (128 px x 64 co: the bf16
+    // MFMA is 16x faster than the fp32 one, so the kernel is bound by L2->LDS staging and LDS fragment reads; the
+    // taller wave tile halves the staged and re-read bytes per MFMA)
+    static constexpr int PR = WM * 2 * WTM;  // patch rows
+    static constexpr int TN = WN * 32 * WTN;
     static constexpr int HALO = CONVT ? 0 : 1;
     static constexpr int HR = PR + 2 * HALO;
     static constexpr int HW = kPW + 2 * HALO;
@@ -75,8 +77,8 @@ struct ConvCfg {
     static constexpr int B_ROUNDS = (B_UNITS + THREADS - 1) / THREADS;
     static constexpr int A_BYTES = HR * HW * ROWB;
     static constexpr int B_BYTES = TN * ROWB;
-    // wave-private weight tiles: each wave stages the 32*WT weight rows it consumes itself (two buffers)
-    static constexpr int BW_ROWS = 32 * WT;
+    // wave-private weight tiles: each wave stages the 32*WTN weight rows it consumes itself (two buffers)
+    static constexpr int BW_ROWS = 32 * WTN;
     static constexpr int BW_BYTES = BW_ROWS * ROWB;
     static constexpr int BP_ROUNDS = BW_ROWS * UPR / 64;
     static constexpr int LDS_BYTES = 2 * A_BYTES + (HOLO_CONV_PRIVATE_B ? WM * WN * 2 * BW_BYTES : 2 * B_BYTES);
@@ -93,11 +95,11 @@ __device__ __forceinline__ int swz_unit(int row, int unit) {
 template <int ROWB>
 __device__ __forceinline__ int swz(int row, int unit) { return row * ROWB + (swz_unit<ROWB>(row, unit) << 4); }
 
-template <int WM, int WN, bool CONVT, int KC, typename T, int WT>
-__global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_kernel(
+template <int WM, int WN, bool CONVT, int KC, typename T, int WTM, int WTN>
+__global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64 ? 1 : HOLO_CONV_MINWAVES)) void conv_mfma_kernel(
     const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
     T* __restrict__ y, int H, int W, int Cin, int Cout, int N, int tiles_x, int tiles_y, int relu, int pool) {
-    using C = ConvCfg<WM, WN, CONVT, KC, T, WT>;
+    using C = ConvCfg<WM, WN, CONVT, KC, T, WTM, WTN>;
     constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_a = smem;                   // [2][A_BYTES]
@@ -200,22 +202,22 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
     // ---- per-lane MFMA operand coordinates -----------------------------------------------------------
     const int hsel = lane >> 5, li = lane & 31;
     const int lpx = (li & 1) | ((li >> 2) << 1);
-    const int lpy = wm * (2 * WT) + ((li >> 1) & 1);  // + 2*mt
-    int b_off[WT];
+    const int lpy = wm * (2 * WTM) + ((li >> 1) & 1);  // + 2*mt
+    int b_off[WTN];
 #pragma unroll
-    for (int nt = 0; nt < WT; ++nt)
-        b_off[nt] = swz<C::ROWB>((HOLO_CONV_PRIVATE_B ? 0 : wn * (32 * WT)) + nt * 32 + li, hsel);
+    for (int nt = 0; nt < WTN; ++nt)
+        b_off[nt] = swz<C::ROWB>((HOLO_CONV_PRIVATE_B ? 0 : wn * (32 * WTN)) + nt * 32 + li, hsel);
 
     // acc: the MFMA chain of the current 16-channel chunk (9 taps x 16 channels = 144 terms);
     // tot: running sum of the finished chunks.  One fp32 fmaf chain over all 9*Cin terms (up to 4608)
     // was measured ~8x noisier against float64 than the CPU reference's blocked sums; folding per chunk
     // shortens every chain to 144 + Cin/16 terms.  (The transposed conv has K = Cin <= 256: no fold.)
     constexpr bool FOLD = !CONVT && F32;   // bf16 inputs dominate the error there: plain fp32 accumulation
-    floatx16 acc[WT][WT], tot[WT][WT];
+    floatx16 acc[WTM][WTN], tot[WTM][WTN];
 #pragma unroll
-    for (int mt = 0; mt < WT; ++mt)
+    for (int mt = 0; mt < WTM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < WT; ++nt)
+        for (int nt = 0; nt < WTN; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[mt][nt][r] = 0.0f;   // live only for the transposed conv (no fold); dead otherwise
@@ -255,9 +257,9 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
             const unsigned char* bbuf = lds_b + bpar * C::B_BYTES;
 #endif
             const int dy = CONVT ? 0 : tap / 3, dx = CONVT ? 0 : tap % 3;   // constants after unrolling
-            int a_off[WT];
+            int a_off[WTM];
 #pragma unroll
-            for (int mt = 0; mt < WT; ++mt) {
+            for (int mt = 0; mt < WTM; ++mt) {
                 const int q = (lpy + 2 * mt + dy) * C::HW + lpx + dx;
                 a_off[mt] = swz<C::ROWB>(q, hsel);
             }
@@ -265,19 +267,19 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
             // swizzle is an XOR on the unit index, so unit 2j+h sits at (offset of unit h) ^ (j << 5)
 #pragma unroll
             for (int j = 0; j < C::UPR / 2; ++j) {
-                float4 av[WT], bv[WT];
+                float4 av[WTM], bv[WTN];
 #pragma unroll
-                for (int mt = 0; mt < WT; ++mt) av[mt] = *reinterpret_cast<const float4*>(abuf + (a_off[mt] ^ (j << 5)));
+                for (int mt = 0; mt < WTM; ++mt) av[mt] = *reinterpret_cast<const float4*>(abuf + (a_off[mt] ^ (j << 5)));
 #pragma unroll
-                for (int nt = 0; nt < WT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bbuf + (b_off[nt] ^ (j << 5)));
+                for (int nt = 0; nt < WTN; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bbuf + (b_off[nt] ^ (j << 5)));
                 if constexpr (F32) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                        for (int mt = 0; mt < WT; ++mt) {
+                        for (int mt = 0; mt < WTM; ++mt) {
                             const float a = k == 0 ? av[mt].x : (k == 1 ? av[mt].y : (k == 2 ? av[mt].z : av[mt].w));
 #pragma unroll
-                            for (int nt = 0; nt < WT; ++nt) {
+                            for (int nt = 0; nt < WTN; ++nt) {
                                 const float b = k == 0 ? bv[nt].x : (k == 1 ? bv[nt].y : (k == 2 ? bv[nt].z : bv[nt].w));
                                 if (FOLD && tap == 0 && j == 0 && k == 0) {
                                     const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -291,9 +293,9 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
                 } else {
                     // lane (r = lane&31, h = lane>>5) holds A[r][k = 8h + e], B[k = 8h + e][r]: the 8 bf16 of unit 2j+h
 #pragma unroll
-                    for (int mt = 0; mt < WT; ++mt)
+                    for (int mt = 0; mt < WTM; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < WT; ++nt)
+                        for (int nt = 0; nt < WTN; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mt]),
                                                                                   __builtin_bit_cast(bf16x8, bv[nt]),
                                                                                   acc[mt][nt], 0, 0, 0);
@@ -301,9 +303,9 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
             }
             if (FOLD && tap == kLast) {
 #pragma unroll
-                for (int mt = 0; mt < WT; ++mt)
+                for (int mt = 0; mt < WTM; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < WT; ++nt) tot[mt][nt] += acc[mt][nt];
+                    for (int nt = 0; nt < WTN; ++nt) tot[mt][nt] += acc[mt][nt];
             }
             HOLO_STAGE_WAIT();                                   // this wave's DMAs (next weights, its share of the next halo)
             if (!HOLO_CONV_PRIVATE_B || tap == kLast) __syncthreads();   // shared data: everybody's DMAs have landed
@@ -314,12 +316,12 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
 
     // ---- epilogue: bias, ReLU, optional 2x2 max-pool, NHWC store ------------------------------------------
 #pragma unroll
-    for (int nt = 0; nt < WT; ++nt) {
-        const int n = n0 + wn * (32 * WT) + nt * 32 + li;  // GEMM column
+    for (int nt = 0; nt < WTN; ++nt) {
+        const int n = n0 + wn * (32 * WTN) + nt * 32 + li;  // GEMM column
         const int co = CONVT ? (n % Cout) : n;
         const float bv = bias[co];
 #pragma unroll
-        for (int mt = 0; mt < WT; ++mt) {
+        for (int mt = 0; mt < WTM; ++mt) {
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
                     const int X = x0 + ((m & 1) | ((m >> 2) << 1));
-                    const int Y = y0 + wm * (2 * WT) + mt * 2 + ((m >> 1) & 1);
+                    const int Y = y0 + wm * (2 * WTM) + mt * 2 + ((m >> 1) & 1);
                     if (X < W && Y < H) yimg[((size_t)(2 * Y + ody) * (2 * W) + (2 * X + odx)) * Cout + co] = (T)v[r];
                 }
             } else if (!pool) {
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
                     const int X = x0 + ((m & 1) | ((m >> 2) << 1));
-                    const int Y = y0 + wm * (2 * WT) + mt * 2 + ((m >> 1) & 1);
+                    const int Y = y0 + wm * (2 * WTM) + mt * 2 + ((m >> 1) & 1);
                     if (X < W && Y < H) yimg[((size_t)Y * W + X) * Cout + co] = (T)v[r];
                 }
             } else {
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
                 // window members beyond the image edge are left out (post-ReLU values are >= 0)
                 const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
                 T* __restrict__ yimg = y + (size_t)img * Ho * Wo * Cout;
-                const int Y = y0 + wm * (2 * WT) + mt * 2;  // even
+                const int Y = y0 + wm * (2 * WTM) + mt * 2;  // even
                 const int PY = Y >> 1;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -376,10 +378,10 @@ __global__ __launch_bounds__(WM * WN * 64, HOLO_CONV_MINWAVES) void conv_mfma_ke
 #undef HOLO_GLDS16
 #undef HOLO_STAGE_WAIT
 
-template <int WM, int WN, bool CONVT, int KC, typename T, int WT = 2>
+template <int WM, int WN, bool CONVT, int KC, typename T, int WTM = 2, int WTN = WTM>
 static int launch_conv(const T* x, const T* wp, const float* bias, T* y, int batch, int h, int w, int cin,
                        int cout, int relu, int pool, hipStream_t stream) {
-    using C = ConvCfg<WM, WN, CONVT, KC, T, WT>;
+    using C = ConvCfg<WM, WN, CONVT, KC, T, WTM, WTN>;
     const int n = CONVT ? 4 * cout : cout;
     const int tiles_x = ceil_div(w, kPW), tiles_y = ceil_div(h, C::PR);
     const long blocks = (long)batch * tiles_x * tiles_y * (n / C::TN);
@@ -387,11 +389,11 @@ static int launch_conv(const T* x, const T* wp, const float* bias, T* y, int bat
     static bool attr_done = false;
     if (!attr_done) {
         if (C::LDS_BYTES > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, CONVT, KC, T, WT>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, CONVT, KC, T, WTM, WTN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, CONVT, KC, T, WT>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, CONVT, KC, T, WTM, WTN>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
                        stream, x, wp, bias, y, h, w, cin, cout, n, tiles_x, tiles_y, relu, pool);
     return check_launch(CONVT ? "holo_convt2x2" : "holo_conv3x3");
 }
@@ -480,14 +482,30 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
                  "holo_conv3x3_%s: one image must stay below 2^31 elements", dtype_name<T>());
     hipStream_t s = as_stream(stream);
     constexpr int KCD = sizeof(T) == 2 ? 32 : 16;   // default K chunk of the dtype
+    // HOLO_CONV_TILE (tests, A/B runs; read per call): 1 = standard tile, 2 = small tile, 3 = tall bf16 wave tile
+    const char* tile_env = getenv("HOLO_CONV_TILE");
+    const int force = tile_env ? atoi(tile_env) : 0;
     // Small problems (e.g. the bundled 5 x 128x128 batches): with the 128-px x 128-co (or 256 x 64) block tile a
     // layer has only 40-320 blocks for 256 CUs.  Below ~2 blocks per CU switch to the 64 px x 64 co tile: 4x
     // the blocks, each a quarter of the work.  Weight packing does not depend on the tile.
     {
         const long big = (long)batch * ceil_div(w, kPW) * (cout % 128 == 0 ? ceil_div(h, 8) * (cout / 128) : ceil_div(h, 16) * (cout / 64));
-        static const int force = [] { const char* e = getenv("HOLO_CONV_TILE"); return e ? atoi(e) : 0; }();  // tests: 1 = big, 2 = small
         if ((force == 2 || (force == 0 && big < 512)) && conv_kc<T>(cin, cout, false) == KCD)
             return launch_conv<2, 2, false, KCD, T, 1>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+    }
+    if constexpr (sizeof(T) == 2) {
+        // Experiment, off unless HOLO_CONV_TILE=3: wave tile 128 px x 64 co (4x2 MFMA tiles; 256 px x 128 co blocks,
+        // or 512 px x 64 co for the 64-wide layers).  It halves the staged and re-read LDS bytes per MFMA, yet measured
+        // SLOWER on MI355X (batch 64, 256x256: 746 TFLOP/s with 64-channel stages / one block per CU, 833 with
+        // 32-channel stages / two blocks per CU, against 898 for the 64 x 64 wave tile): results are bit-identical.
+        const bool wide = cout % 128 == 0;
+        const bool narrow = cout % 128 != 0 && conv_kc<T>(cin, cout, false) == 32;
+        if ((wide || narrow) && force == 3) {
+            if (wide && conv_kc<T>(cin, cout, false) == 64)
+                return launch_conv<2, 2, false, 64, T, 4, 2>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+            if (wide) return launch_conv<2, 2, false, 32, T, 4, 2>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+            return launch_conv<4, 1, false, 32, T, 4, 2>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+        }
     }
     if (cout % 128 == 0) {
         if (conv_kc<T>(cin, cout, false) == 2 * KCD)   // the deeper-stage variant of this dtype

@@ -1,7 +1,8 @@
-// The two skinny layers that cannot feed the matrix cores (K = 27 and N = 2): direct fp32 VALU kernels.
+// The two skinny layers (K = 27 and N = 2).
 //
 //   holo_conv_first_f32 : vgg[0:4]  Conv2d(1,3,1x1) -> ReflectionPad2d(1) -> Conv2d(3,64,3x3) -> ReLU
-//                         (net.py:77-80), single-channel planes in, NHWC 64-channel out.  Output-write bound.
+//                         (net.py:77-80), single-channel planes in, NHWC 64-channel out.  Output-write bound
+//                         (fp32 MFMA with K = 27).
 //   holo_conv_last_f32  : decoder[36:38]  ReflectionPad2d(1) -> Conv2d(64,2,3x3), no activation (net.py:72-73),
 //                         NHWC in, NCHW amplitude/phase planes out.  Input-read bound.
 #include "common.h"
@@ -12,63 +13,102 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// 16 lanes share a pixel (4 output channels each) so one store instruction writes whole 256-B pixels.
-// Each thread keeps its 27x4 weights in registers and walks pixels with a grid stride.
+// First layer on the matrix cores.  K = 27 (3 channels x 9 taps, padded to 28) is tiny, but as a direct VALU kernel the
+// layer costs 108 FMAs per lane and pixel and was compute-bound (0.48 ms at batch 64 x 256^2, 7.9 ms at 256 x 512^2);
+// as 14 steps of v_mfma_f32_32x32x2_f32 per 32 px x 32 co tile it is bound by its 64-channel output write.
+// Block = 16x16 output pixels, 4 waves; a wave owns 4 rows = two 32-pixel M tiles (m = 16*(row&1) + x) x 64 co.
+//   A[m][k]  = w0[c]*in(pixel + tap) + b0[c], k = 9c + tap: vgg[0] applied on the fly to the reflect-padded halo in LDS
+//   B[k][co] = w1[co][k] (OIHW is already [co][27]); k = 27 is a zero column
+// fp32 accumulation for both output types; the tile goes through LDS once more so that every pixel's 64 channels
+// leave as whole 16-byte units of one contiguous NHWC run.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int kFT = 16;            // tile side
+constexpr int kFH = kFT + 2;       // halo side
+constexpr int kFK = 28;            // padded K
+constexpr int kFWS = 29;           // LDS row stride of the weights (odd: conflict-free column reads)
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                          const float* __restrict__ b0, const float* __restrict__ w1,
-                                                         const float* __restrict__ b1, T* __restrict__ y,
-                                                         long total_px, int H, int W) {
-    const int tid = threadIdx.x;
-    const int cq = tid & 15;   // output channels 4*cq .. 4*cq+3
-    const int pl = tid >> 4;   // pixel slot within the block (16 per block)
-    float wreg[27][4];
+                                                         const float* __restrict__ b1, T* __restrict__ y, int H, int W,
+                                                         int tiles_x, int tiles_y) {
+    __shared__ float halo[kFH * kFH];
+    __shared__ float wl[64 * kFWS];
+    __shared__ __attribute__((aligned(16))) T stage[4][32 * 64];   // per wave: one M tile as [pixel][co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int x0 = tx * kFT, y0 = ty * kFT;
+    const float* __restrict__ xi = x + (size_t)img * H * W;
+    for (int i = tid; i < kFH * kFH; i += 256) {
+        const int hy = i / kFH, hx = i % kFH;
+        halo[i] = xi[reflect1(y0 - 1 + hy, H) * W + reflect1(x0 - 1 + hx, W)];
+    }
+    for (int i = tid; i < 64 * kFK; i += 256) {
+        const int co = i / kFK, k = i % kFK;
+        wl[co * kFWS + k] = k < 27 ? w1[co * 27 + k] : 0.0f;
+    }
+    __syncthreads();
+
+    // this lane's K column per MFMA step: k = 2j + (lane>>5)
+    const int hsel = lane >> 5, r = lane & 31;
+    int koff[kFK / 2];
+    float kw[kFK / 2], kb[kFK / 2];
 #pragma unroll
-    for (int k = 0; k < 27; ++k)
+    for (int j = 0; j < kFK / 2; ++j) {
+        int k = 2 * j + hsel;
+        k = k < 27 ? k : 0;                   // the padded column multiplies a zero weight: any finite value does
+        const int c = k / 9, tap = k % 9;
+        koff[j] = (tap / 3) * kFH + tap % 3;
+        kw[j] = w0[c];
+        kb[j] = b0[c];
+    }
+    const int lx = r & 15, ly = r >> 4;
+    float bias[2];
+    bias[0] = b1[r], bias[1] = b1[32 + r];
+    T* __restrict__ yimg = y + (size_t)img * H * W * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wreg[k][j] = w1[(4 * cq + j) * 27 + k];  // OIHW (64,3,3,3): k = c*9 + ky*3 + kx
-    float breg[4];
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = 4 * wave + 2 * mt;       // first of the tile's two rows
+        floatx16 acc[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) breg[j] = b1[4 * cq + j];
-    const float w00 = w0[0], w01 = w0[1], w02 = w0[2];
-    const float b00 = b0[0], b01 = b0[1], b02 = b0[2];
-    const long hw = (long)H * W;
-    for (long p = (long)blockIdx.x * 16 + pl; p < total_px; p += (long)gridDim.x * 16) {
-        const long img = p / hw;
-        const int rem = (int)(p % hw);
-        const int py = rem / W, px = rem % W;
-        const float* __restrict__ xi = x + img * hw;
-        float acc[4] = {breg[0], breg[1], breg[2], breg[3]};
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int ry = reflect1(py + ky - 1, H);
+            for (int q = 0; q < 16; ++q) acc[nt][q] = 0.0f;
+        const int hbase = (row + ly) * kFH + lx;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int rx = reflect1(px + kx - 1, W);
-                const float v = xi[ry * W + rx];
-                // vgg[0]: per-pixel affine 1 -> 3 (reflection padding commutes with it)
-                const float t0 = v * w00 + b00, t1 = v * w01 + b01, t2 = v * w02 + b02;
-                const int k = ky * 3 + kx;
+        for (int j = 0; j < kFK / 2; ++j) {
+            const float a = halo[hbase + koff[j]] * kw[j] + kb[j];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[j] += t0 * wreg[k][j];
-                    acc[j] += t1 * wreg[9 + k][j];
-                    acc[j] += t2 * wreg[18 + k][j];
-                }
+            for (int nt = 0; nt < 2; ++nt) {
+                const float b = wl[(nt * 32 + r) * kFWS + 2 * j + hsel];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
             }
         }
-        if constexpr (sizeof(T) == 4) {
-            float4 o;
-            o.x = fmaxf(acc[0], 0.0f);
-            o.y = fmaxf(acc[1], 0.0f);
-            o.z = fmaxf(acc[2], 0.0f);
-            o.w = fmaxf(acc[3], 0.0f);
-            *reinterpret_cast<float4*>(y + p * 64 + 4 * cq) = o;
-        } else {
-            const bf16x4 o = {(bf16_t)fmaxf(acc[0], 0.0f), (bf16_t)fmaxf(acc[1], 0.0f), (bf16_t)fmaxf(acc[2], 0.0f),
-                              (bf16_t)fmaxf(acc[3], 0.0f)};
-            *reinterpret_cast<bf16x4*>(y + p * 64 + 4 * cq) = o;
+        // C layout: pixel m = (q&3) + 8*(q>>2) + 4*hsel, channel n = r (+32 for the second N tile)
+        T* st = stage[wave];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = (q & 3) + 8 * (q >> 2) + 4 * hsel;
+                st[m * 64 + nt * 32 + r] = (T)fmaxf(acc[nt][q] + bias[nt], 0.0f);
+            }
+        __syncthreads();
+        // 32 pixels x 64 channels = 32 * 64 * sizeof(T) / 16 units of 16 bytes; a lane takes every 64th
+        constexpr int UPP = 64 * (int)sizeof(T) / 16;    // units per pixel (16 fp32 / 8 bf16)
+#pragma unroll
+        for (int u = lane; u < 32 * UPP; u += 64) {
+            const int m = u / UPP, c = u % UPP;
+            const int X = x0 + (m & 15), Y = y0 + row + (m >> 4);
+            if (X < W && Y < H)
+                *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(yimg + ((size_t)Y * W + X) * 64) + 16 * c) =
+                    *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(st + m * 64) + 16 * c);
         }
+        __syncthreads();
     }
 }
 
@@ -150,11 +190,11 @@ static int conv_first_entry(const float* x, const float* w0, const float* b0, co
     HOLO_REQUIRE(x && w0 && b0 && w1 && b1 && y_nhwc, HOLO_ERR_ARG, "holo_conv_first: null pointer");
     HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG,
                  "holo_conv_first: batch=%d h=%d w=%d (reflection padding needs h,w >= 2)", batch, h, w);
-    const long total = (long)batch * h * w;
-    long blocks = (total + 15) / 16;
-    if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride the rest
+    const int tiles_x = ceil_div(w, kFT), tiles_y = ceil_div(h, kFT);
+    const long blocks = (long)batch * tiles_x * tiles_y;
+    HOLO_REQUIRE(blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "holo_conv_first: grid of %ld blocks", blocks);
     hipLaunchKernelGGL((conv_first_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, w0, b0, w1, b1,
-                       y_nhwc, total, h, w);
+                       y_nhwc, h, w, tiles_x, tiles_y);
     return check_launch("holo_conv_first");
 }
 

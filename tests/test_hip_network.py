@@ -184,6 +184,24 @@ def test_entry_script_runs_the_bundled_data(tmp_path, monkeypatch, capsys):
     assert (w, h) == (512, 256)            # 4 x 128 wide, 2 x 128 tall mosaics like the reference's
 
 
+def test_entry_script_default_unwraps_on_the_device(tmp_path, monkeypatch, capsys):
+    """Default flags, as the reference runs it (unwrap=True at test_field_retrieval_mnist.py:126): the focused phase is
+    unwrapped by holo_unwrap2d_f32; the printed metrics stay finite and, the bundled phases being far below pi, equal
+    the ones of the wrapped run to the printed precision unless a focused phase really wraps."""
+    import re
+    import test_field_retrieval_mnist as entry
+    monkeypatch.chdir(REPO)
+    vals = {}
+    for mode in ("on", "off"):
+        rc = entry.main(["--device", "cuda", "--synthetic-weights", "0", "--save_dir", str(tmp_path / mode), "--no-images"]
+                        + ([] if mode == "on" else ["--unwrap", "off"]))
+        out = capsys.readouterr().out
+        assert rc == 0
+        vals[mode] = [float(v) for v in re.findall(r"(?:Mean PSNR|Mean MAE|R2 score):\s+([-+0-9.eE]+)", out)]
+        assert len(vals[mode]) == 3 and all(v == v and abs(v) < 1e9 for v in vals[mode])
+    assert vals["on"][2] == vals["off"][2]                     # the distance head does not see the unwrapping
+
+
 def test_module_plumbing_matches_reference_usage(env, mnist_style):
     """The entry script's plumbing (test_field_retrieval_mnist.py:76-94): deepcopy of net.decoder, load_state_dict,
     children()[:31] slicing, .eval().to(device); a state_dict round trip on the device keeps results bit-exact and a

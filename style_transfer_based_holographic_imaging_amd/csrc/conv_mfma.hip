@@ -35,6 +35,9 @@
 #define HOLO_CONV_PRIVATE_B 0   // 0: block-shared weight tile, one barrier per tap (default: measured faster);
                                 // 1: every wave DMAs its own weight rows, barrier only per chunk (-5 % fp32, -19 % bf16)
 #endif
+#ifndef HOLO_CONV_ABLATE
+#define HOLO_CONV_ABLATE 0   // timing experiments only (results are garbage): 1 = no staging loads in the main loop, 2 = no stage waits/barriers
+#endif
 #ifndef HOLO_CONV_SETPRIO
 #define HOLO_CONV_SETPRIO 0
 #endif
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
     }
 #define HOLO_LOAD_A(chunk_, buf_)                                                                         \
     _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
-        if (tid + r * C::THREADS < C::A_UNITS)                                                            \
+        if (C::A_UNITS % C::THREADS == 0 || tid + r * C::THREADS < C::A_UNITS)                            \
             HOLO_GLDS16(ximg + a_src[r] + (chunk_) * KC,                                                 \
                         (buf_) * C::A_BYTES + r * C::THREADS * 16 + wave_base)                           \
     }
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
 #define HOLO_LOAD_B(wsrc_, buf_)                                                                          \
     {                                                                                                     \
         _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                         \
-            if (tid + r * C::THREADS < C::B_UNITS)                                                        \
+            if (C::B_UNITS % C::THREADS == 0 || tid + r * C::THREADS < C::B_UNITS)                        \
                 HOLO_GLDS16((wsrc_) + b_src[r], 2 * C::A_BYTES + (buf_) * C::B_BYTES + r * C::THREADS * 16 + wave_base) \
         }                                                                                                 \
     }
@@ -244,11 +247,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
         for (int tap = 0; tap < C::TAPS; ++tap) {
             constexpr int kLast = C::TAPS - 1;
             const bool has_next = tap != kLast || more_chunks;
-            if (has_next) {
-                wsrc += w_stage;
-                HOLO_LOAD_B(wsrc, bpar ^ 1)
-            }
-            if (tap == kLast && more_chunks) { HOLO_LOAD_A(chunk + 1, apar ^ 1) }
 
             const unsigned char* abuf = lds_a + apar * C::A_BYTES;
 #if HOLO_CONV_PRIVATE_B
@@ -272,6 +270,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
                 for (int mt = 0; mt < WTM; ++mt) av[mt] = *reinterpret_cast<const float4*>(abuf + (a_off[mt] ^ (j << 5)));
 #pragma unroll
                 for (int nt = 0; nt < WTN; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bbuf + (b_off[nt] ^ (j << 5)));
+#if !(HOLO_CONV_ABLATE & 1)
+                if (j == 0) {
+                    // the staging loads of the next stage are issued behind the first fragment reads, so their issue
+                    // slots fall into the LDS latency the first MFMA waits for anyway (ablation: loads in front of the
+                    // reads cost 5.6 % of the kernel, the per-stage barrier nothing)
+                    if (has_next) {
+                        wsrc += w_stage;
+                        HOLO_LOAD_B(wsrc, bpar ^ 1)
+                    }
+                    if (tap == kLast && more_chunks) { HOLO_LOAD_A(chunk + 1, apar ^ 1) }
+                }
+#endif
                 if constexpr (F32) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -307,8 +317,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
 #pragma unroll
                     for (int nt = 0; nt < WTN; ++nt) tot[mt][nt] += acc[mt][nt];
             }
+#if !(HOLO_CONV_ABLATE & 2)
             HOLO_STAGE_WAIT();                                   // this wave's DMAs (next weights, its share of the next halo)
             if (!HOLO_CONV_PRIVATE_B || tap == kLast) __syncthreads();   // shared data: everybody's DMAs have landed
+#endif
             bpar ^= 1;
         }
         apar ^= 1;

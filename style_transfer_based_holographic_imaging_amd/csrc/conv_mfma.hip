@@ -159,11 +159,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
     for (int r = 0; r < C::B_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
         const int co = u / C::UPR, c = swz_unit<C::ROWB>(co, u % C::UPR);
-        b_src[r] = co * KC + C::EPU * c;
+        b_src[r] = (co * KC + C::EPU * c) * C::ES;   // byte offset within a [N][KC] weight tile
     }
 #endif
     // global_load_lds_dwordx4: no staging VGPRs, no ds_write; completion = s_waitcnt vmcnt(0)
-    const int wave_base = (tid & ~63) * 16;   // byte offset of this wave's first unit within a block-wide round
+    // byte offset of this wave's first unit within a block-wide round: wave-uniform, kept in an SGPR so that LDS
+    // destinations are pure scalar arithmetic
+    const int wave_base = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
     const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
 // Issued from inline asm on purpose: through the builtin, hipcc orders every later ds_read behind the
 // pending LDS write and drains vmcnt(0) before the first fragment read of the stage (seen in the ISA),
@@ -177,6 +179,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
                      "s_mov_b32 m0, %0"                                                                    \
                      : "=&s"(m0_keep)                                                                     \
                      : "v"(gsrc_), "s"(lds_u)                                                             \
+                     : "memory");                                                                         \
+    }
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: no per-load VALU address arithmetic
+#define HOLO_GLDS16_S(sbase_, voff_, ldst_)                                                                \
+    {                                                                                                     \
+        unsigned m0_keep;                                                                                 \
+        const unsigned lds_u = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(ldst_));              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t" \
+                     "s_mov_b32 m0, %0"                                                                    \
+                     : "=&s"(m0_keep)                                                                     \
+                     : "v"(voff_), "s"(sbase_), "s"(lds_u)                                                \
                      : "memory");                                                                         \
     }
 #define HOLO_LOAD_A(chunk_, buf_)                                                                         \
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
     {                                                                                                     \
         _Pragma("unroll") for (int r = 0; r < C::B_ROUNDS; ++r) {                                         \
             if (C::B_UNITS % C::THREADS == 0 || tid + r * C::THREADS < C::B_UNITS)                        \
-                HOLO_GLDS16((wsrc_) + b_src[r], 2 * C::A_BYTES + (buf_) * C::B_BYTES + r * C::THREADS * 16 + wave_base) \
+                HOLO_GLDS16_S((wsrc_), b_src[r], 2 * C::A_BYTES + (buf_) * C::B_BYTES + r * C::THREADS * 16 + wave_base) \
         }                                                                                                 \
     }
 #endif
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
 #undef HOLO_LOAD_A
 #undef HOLO_LOAD_B
 #undef HOLO_GLDS16
+#undef HOLO_GLDS16_S
 #undef HOLO_STAGE_WAIT
 
 template <int WM, int WN, bool CONVT, int KC, typename T, int WTM = 2, int WTN = WTM>

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
     // 16-byte unit u = tid + r*THREADS of the LDS image holds unit (u&3) ^ swizzle of halo pixel / output
     // channel u>>2.  With LDS-DMA the destination is lane-linear (wave base + lane*16), so the XOR swizzle
     // is applied to the per-lane SOURCE address; the ds_read side applies the same XOR (swz()).
-    int a_src[C::A_ROUNDS];
+    unsigned a_src[C::A_ROUNDS];
 #pragma unroll
     for (int r = 0; r < C::A_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
         const int hy = q / C::HW, hx = q % C::HW;
         const int ry = reflect1(y0 - C::HALO + hy, H);
         const int rx = reflect1(x0 - C::HALO + hx, W);
-        a_src[r] = (ry * W + rx) * Cin + C::EPU * c;
+        a_src[r] = (unsigned)((ry * W + rx) * Cin + C::EPU * c) * (unsigned)C::ES;   // byte offset within the image (< 2^32: entry check)
     }
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
 #define HOLO_LOAD_A(chunk_, buf_)                                                                         \
     _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                             \
         if (C::A_UNITS % C::THREADS == 0 || tid + r * C::THREADS < C::A_UNITS)                            \
-            HOLO_GLDS16(ximg + a_src[r] + (chunk_) * KC,                                                 \
-                        (buf_) * C::A_BYTES + r * C::THREADS * 16 + wave_base)                           \
+            HOLO_GLDS16_S(ximg + (chunk_) * KC, a_src[r],                                      \
+                          (buf_) * C::A_BYTES + r * C::THREADS * 16 + wave_base)                         \
     }
 #if HOLO_CONV_PRIVATE_B
 #define HOLO_LOAD_B(wsrc_, buf_)                                                                          \
@@ -504,8 +504,8 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
     HOLO_REQUIRE(cin > 0 && cin % min_cin<T>() == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
                  "holo_conv3x3_%s: Cin=%d must be a multiple of %d and Cout=%d of 64", dtype_name<T>(), cin, min_cin<T>(), cout);
     HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_%s: fused pooling requires relu", dtype_name<T>());
-    HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
-                 "holo_conv3x3_%s: one image must stay below 2^31 elements", dtype_name<T>());
+    HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < (1L << 30), HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_%s: one image must stay below 2^30 elements (32-bit byte offsets)", dtype_name<T>());
     hipStream_t s = as_stream(stream);
     constexpr int KCD = sizeof(T) == 2 ? 32 : 16;   // default K chunk of the dtype
     // HOLO_CONV_TILE (tests, A/B runs; read per call): 1 = standard tile, 2 = small tile, 3 = tall bf16 wave tile
@@ -548,8 +548,8 @@ static int convt2x2_entry(const T* x_nhwc, const T* w_packed, const float* bias,
     HOLO_REQUIRE(batch > 0 && h >= 1 && w >= 1, HOLO_ERR_ARG, "holo_convt2x2_%s: batch=%d h=%d w=%d", dtype_name<T>(), batch, h, w);
     HOLO_REQUIRE(cin > 0 && cin % min_cin<T>() == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
                  "holo_convt2x2_%s: Cin=%d must be a multiple of %d and Cout=%d of 64", dtype_name<T>(), cin, min_cin<T>(), cout);
-    HOLO_REQUIRE((long)h * w * 4 * (cin > cout ? cin : cout) < 2147483647L, HOLO_ERR_UNSUPPORTED,
-                 "holo_convt2x2_%s: one image must stay below 2^31 elements", dtype_name<T>());
+    HOLO_REQUIRE((long)h * w * 4 * (cin > cout ? cin : cout) < (1L << 30), HOLO_ERR_UNSUPPORTED,
+                 "holo_convt2x2_%s: one image must stay below 2^30 elements (32-bit byte offsets)", dtype_name<T>());
     // a 128-wide N tile would straddle two (dy,dx) quadrants when Cout % 128 != 0: use the 64-wide tile then
     hipStream_t s = as_stream(stream);
     constexpr int KCD = sizeof(T) == 2 ? 32 : 16;

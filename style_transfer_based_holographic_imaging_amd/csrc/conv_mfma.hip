@@ -461,7 +461,8 @@ __global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict_
 #define HOLO_CONV_KC32 0
 #endif
 #ifndef HOLO_CONV_BF16_KC64
-#define HOLO_CONV_BF16_KC64 1   // bf16, 128-wide tile: 64-channel stages (128-B LDS rows): twice the MFMAs per barrier
+#define HOLO_CONV_BF16_KC64 0   // 1: bf16, 128-wide tile with 64-channel stages (128-B LDS rows, twice the MFMAs per barrier).  Was +2 % with
+                                // the first staging code; with scalar-base staging loads 32-channel stages (3 blocks per CU) are 1.4 % ahead
 #endif
 template <typename T>
 static int conv_kc(int cin, int cout, bool convt) {

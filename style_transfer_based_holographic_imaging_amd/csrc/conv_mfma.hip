@@ -98,6 +98,17 @@ __device__ __forceinline__ int swz_unit(int row, int unit) {
 template <int ROWB>
 __device__ __forceinline__ int swz(int row, int unit) { return row * ROWB + (swz_unit<ROWB>(row, unit) << 4); }
 
+// Halo (A operand) tile, 64-B rows.  ds_read_b128 is served in four groups of 16 NON-contiguous lanes ({0-3,12-15,20-27},
+// {4-11,16-19,28-31} and the same + 32) over 64 banks, i.e. 16 slots of 16 B; a row holds 4 slots, the quad chosen by the
+// row index mod 4.  With the tile -> pixel mapping below a group reads 8 pixel columns on each of 2 pixel rows, and the
+// row-index swizzle above put two of them on one slot for every tap (2 LDS cycles per group: the constant 0.333
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the first profiles).  Keyed on the pixel coordinates instead — bit 2 of the
+// column and the parity of the row — the 16 lanes of a group fall on 16 different slots for all nine taps.
+template <int ROWB>
+__device__ __forceinline__ int swz_a_unit(int hx, int hy, int q, int unit) {
+    return ROWB == 64 ? (unit ^ (((hx >> 2) & 1) | ((hy & 1) << 1))) : swz_unit<ROWB>(q, unit);
+}
+
 template <int WM, int WN, bool CONVT, int KC, typename T, int WTM, int WTN>
 __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64 ? 1 : HOLO_CONV_MINWAVES)) void conv_mfma_kernel(
     const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
@@ -130,8 +141,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
 #pragma unroll
     for (int r = 0; r < C::A_ROUNDS; ++r) {
         const int u = tid + r * C::THREADS;
-        const int q = u / C::UPR, c = swz_unit<C::ROWB>(q, u % C::UPR);
+        const int q = u / C::UPR;
         const int hy = q / C::HW, hx = q % C::HW;
+        const int c = swz_a_unit<C::ROWB>(hx, hy, q, u % C::UPR);
         const int ry = reflect1(y0 - C::HALO + hy, H);
         const int rx = reflect1(x0 - C::HALO + hx, W);
         a_src[r] = (unsigned)((ry * W + rx) * Cin + C::EPU * c) * (unsigned)C::ES;   // byte offset within the image (< 2^32: entry check)
@@ -271,8 +283,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
             int a_off[WTM];
 #pragma unroll
             for (int mt = 0; mt < WTM; ++mt) {
-                const int q = (lpy + 2 * mt + dy) * C::HW + lpx + dx;
-                a_off[mt] = swz<C::ROWB>(q, hsel);
+                const int hy = lpy + 2 * mt + dy, hx = lpx + dx;
+                const int q = hy * C::HW + hx;
+                a_off[mt] = q * C::ROWB + (swz_a_unit<C::ROWB>(hx, hy, q, hsel) << 4);
             }
             // lanes 0-31 read unit 2j, lanes 32-63 unit 2j+1 (the k = lane>>5 split of the 32x32x2 MFMA); the
             // swizzle is an XOR on the unit index, so unit 2j+h sits at (offset of unit h) ^ (j << 5)

@@ -332,8 +332,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
                     for (int mt = 0; mt < WTM; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < WTN; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[mt]),
-                                                                                  __builtin_bit_cast(bf16x8, bv[nt]),
+                            // operands swapped: D[m = channel][n = pixel], so a lane ends up with 16 channels of ONE pixel and
+                            // the epilogue can store 16-byte pieces of an NHWC pixel (see the bf16 epilogue)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv[nt]),
+                                                                                  __builtin_bit_cast(bf16x8, av[mt]),
                                                                                   acc[mt][nt], 0, 0, 0);
                 }
             }
@@ -350,6 +352,81 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
             bpar ^= 1;
         }
         apar ^= 1;
+    }
+
+    // ---- bf16 epilogue ---------------------------------------------------------------------------------------------
+    // The bf16 product is computed transposed: lane = pixel (tile column li), registers = channels
+    // (r&3) + 8*(r>>2) + 4*hsel of the 32-channel tile.  Each quad of registers is 4 consecutive channels = 8 bytes of
+    // bf16; lanes l and l+32 hold neighbouring quads of the same pixel, so one v_permlane32_swap per dword turns two
+    // quads into one 16-byte run per lane: 2 x global_store_dwordx4 per tile instead of 16 two-byte stores (without
+    // its stores the bf16 kernel ran 14 % faster, the transposed conv 2x: the epilogue was store-issue bound).
+    if constexpr (!F32) {
+        const int px_x = x0 + lpx;
+        const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+#pragma unroll
+        for (int mt = 0; mt < WTM; ++mt) {
+            const int X = px_x, Y = y0 + wm * (2 * WTM) + 2 * mt + ((li >> 1) & 1);
+            const bool inside = X < W && Y < H;
+#pragma unroll
+            for (int nt = 0; nt < WTN; ++nt) {
+                const int cbase = n0 + wn * (32 * WTN) + nt * 32;          // first GEMM column of this tile (wave-uniform)
+                const int co_base = CONVT ? cbase % Cout : cbase;
+                const int qd = CONVT ? cbase / Cout : 0;                    // (dy,dx) quadrant of a transposed conv
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + co_base + 8 * q + 4 * hsel);
+                    const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = acc[mt][nt][4 * q + i] + bq[i];
+                        v[4 * q + i] = relu ? fmaxf(t, 0.0f) : t;
+                    }
+                }
+                bool writer = inside;
+                size_t pix;                                                  // output pixel index (in pixels)
+                T* __restrict__ yimg;
+                if (CONVT) {
+                    yimg = y + (size_t)img * (2 * H) * (2 * W) * Cout;
+                    pix = (size_t)(2 * Y + (qd >> 1)) * (2 * W) + (2 * X + (qd & 1));
+                } else if (!pool) {
+                    yimg = y + (size_t)img * H * W * Cout;
+                    pix = (size_t)Y * W + X;
+                } else {
+                    // MaxPool2d(2,2,ceil_mode=True): the window is the 4 lanes 4g..4g+3 (x bit0 = lane bit0, y bit0 = lane
+                    // bit1).  Members beyond the image edge count as 0 (pooling follows a ReLU: values are >= 0).
+                    yimg = y + (size_t)img * Ho * Wo * Cout;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float t = inside ? v[r] : 0.0f;
+                        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true)));  // quad_perm [1,0,3,2]
+                        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true)));  // quad_perm [2,3,0,1]
+                        v[r] = t;
+                    }
+                    writer = inside && (li & 3) == 0;                       // the window's top-left pixel stores
+                    pix = (size_t)(Y >> 1) * Wo + (X >> 1);
+                }
+                unsigned pk[8];                                              // quad q -> dwords 2q, 2q+1 (bf16 pairs)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    const bf16x2 two = {(bf16_t)v[2 * d], (bf16_t)v[2 * d + 1]};
+                    pk[d] = __builtin_bit_cast(unsigned, two);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    // quads 2k (dwords 4k, 4k+1) and 2k+1 (dwords 4k+2, 4k+3): swap the upper half-wave's first quad with
+                    // the lower half-wave's second one
+                    auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * k], pk[4 * k + 2], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * k + 1], pk[4 * k + 3], false, false);
+                    const uint4 chunk = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    // lower half-wave: channels 16k .. 16k+7, upper half-wave: 16k+8 .. 16k+15 of this pixel
+                    if (writer)
+                        *reinterpret_cast<uint4*>(yimg + pix * Cout + co_base + 16 * k + 8 * hsel) = chunk;
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: bias, ReLU, optional 2x2 max-pool, NHWC store ------------------------------------------

@@ -241,6 +241,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
     // was measured ~8x noisier against float64 than the CPU reference's blocked sums; folding per chunk
     // shortens every chain to 144 + Cin/16 terms.  (The transposed conv has K = Cin <= 256: no fold.)
     constexpr bool FOLD = !CONVT && F32;   // bf16 inputs dominate the error there: plain fp32 accumulation
+    // transposed product (lane = pixel, registers = channels) wherever the epilogue's stores matter: all bf16 layers and
+    // the fp32 transposed conv (4x the output pixels of its input, K = Cin only)
+    constexpr bool TRANSPOSED = !F32 || CONVT;
     floatx16 acc[WTM][WTN], tot[WTM][WTN];
 #pragma unroll
     for (int mt = 0; mt < WTM; ++mt)
@@ -320,6 +323,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
                                 if (FOLD && tap == 0 && j == 0 && k == 0) {
                                     const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, zero, 0, 0, 0);
+                                } else if (TRANSPOSED) {   // same products in the same k order: bit-identical, D[channel][pixel]
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[mt][nt], 0, 0, 0);
                                 } else {
                                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt][nt], 0, 0, 0);
                                 }
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
     // bf16; lanes l and l+32 hold neighbouring quads of the same pixel, so one v_permlane32_swap per dword turns two
     // quads into one 16-byte run per lane: 2 x global_store_dwordx4 per tile instead of 16 two-byte stores (without
     // its stores the bf16 kernel ran 14 % faster, the transposed conv 2x: the epilogue was store-issue bound).
-    if constexpr (!F32) {
+    if constexpr (TRANSPOSED) {
         const int px_x = x0 + lpx;
         const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
 #pragma unroll
@@ -405,6 +410,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
                     }
                     writer = inside && (li & 3) == 0;                       // the window's top-left pixel stores
                     pix = (size_t)(Y >> 1) * Wo + (X >> 1);
+                }
+                if constexpr (F32) {
+                    // fp32: a quad of registers is already a 16-byte run of the pixel
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (writer)
+                            *reinterpret_cast<float4*>(yimg + pix * Cout + co_base + 8 * q + 4 * hsel) =
+                                make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    continue;
                 }
                 unsigned pk[8];                                              // quad q -> dwords 2q, 2q+1 (bf16 pairs)
 #pragma unroll

@@ -47,6 +47,15 @@ namespace holo {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+// EXPERIMENT (holo_conv3x3_f32s): an fp32 value as two fp16 halves, a = hi + lo' * 2^-11 (22-23 significant bits), stored
+// planar per 16-channel group: [16 x hi | 16 x lo'] = 64 bytes per group, so a lane's 16-byte fragment read is 8 consecutive
+// channels of one half, exactly one operand of v_mfma_f32_32x32x16_f16
+struct split16 {
+    _Float16 hi, lo;
+    split16() = default;
+    __host__ __device__ explicit split16(float f) : hi((_Float16)f), lo((_Float16)0.0f) {}   // only so that dead store paths compile
+};
 
 constexpr int kKC = 16;  // smallest K chunk (channels); weights/activations need Cin % 16 == 0
 constexpr int kPW = 16;  // patch width in pixels
@@ -110,11 +119,12 @@ __device__ __forceinline__ int swz_a_unit(int hx, int hy, int q, int unit) {
 }
 
 template <int WM, int WN, bool CONVT, int KC, typename T, int WTM, int WTN>
-__global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64 ? 1 : HOLO_CONV_MINWAVES)) void conv_mfma_kernel(
+__global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 64) || __is_same(T, split16) ? 1 : HOLO_CONV_MINWAVES)) void conv_mfma_kernel(
     const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
     T* __restrict__ y, int H, int W, int Cin, int Cout, int N, int tiles_x, int tiles_y, int relu, int pool) {
     using C = ConvCfg<WM, WN, CONVT, KC, T, WTM, WTN>;
-    constexpr bool F32 = sizeof(T) == 4;
+    constexpr bool SPLIT = __is_same(T, split16);
+    constexpr bool F32 = sizeof(T) == 4 && !SPLIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_a = smem;                   // [2][A_BYTES]
     unsigned char* lds_b = smem + 2 * C::A_BYTES;  // [2][B_BYTES]
@@ -240,11 +250,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
     // tot: running sum of the finished chunks.  One fp32 fmaf chain over all 9*Cin terms (up to 4608)
     // was measured ~8x noisier against float64 than the CPU reference's blocked sums; folding per chunk
     // shortens every chain to 144 + Cin/16 terms.  (The transposed conv has K = Cin <= 256: no fold.)
-    constexpr bool FOLD = !CONVT && F32;   // bf16 inputs dominate the error there: plain fp32 accumulation
+    constexpr bool FOLD = !CONVT && (F32 || SPLIT);   // bf16 inputs dominate the error there: plain fp32 accumulation
     // transposed product (lane = pixel, registers = channels) wherever the epilogue's stores matter: all bf16 layers and
     // the fp32 transposed conv (4x the output pixels of its input, K = Cin only)
-    constexpr bool TRANSPOSED = !F32 || CONVT;
+    constexpr bool TRANSPOSED = !F32 || CONVT;   // (split operands: transposed as well, fp32 quads out)
     floatx16 acc[WTM][WTN], tot[WTM][WTN];
+    floatx16 accx[SPLIT ? WTM : 1][SPLIT ? WTN : 1];   // split operands: hi*lo' + lo'*hi, scaled by 2^-11 at the fold
 #pragma unroll
     for (int mt = 0; mt < WTM; ++mt)
 #pragma unroll
@@ -268,6 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
     HOLO_STAGE_WAIT();
     __syncthreads();
 
+    float4 ah[WTM], bh[WTN];   // split operands: the hi fragments of the current 16-channel group
     int apar = 0, bpar = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more_chunks = chunk + 1 < nchunks;
@@ -311,7 +323,30 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
                     if (tap == kLast && more_chunks) { HOLO_LOAD_A(chunk + 1, apar ^ 1) }
                 }
 #endif
-                if constexpr (F32) {
+                if constexpr (SPLIT) {
+                    // j-th pair of 16-byte units = half a 16-channel group: even j -> hi units, odd j -> lo' units of group j/2
+                    // (unit 4g + h = hi, 4g + 2 + h = lo').  The MFMAs run when both halves of a group are in registers.
+                    static_assert(!SPLIT || (C::UPR % 4 == 0), "split rows hold whole 16-channel groups");
+                    if ((j & 1) == 0) {
+#pragma unroll
+                        for (int mt = 0; mt < WTM; ++mt) ah[mt] = av[mt];
+#pragma unroll
+                        for (int nt = 0; nt < WTN; ++nt) bh[nt] = bv[nt];
+                    } else {
+#pragma unroll
+                        for (int mt = 0; mt < WTM; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < WTN; ++nt) {
+                                const halfx8 a_hi = __builtin_bit_cast(halfx8, ah[mt]), a_lo = __builtin_bit_cast(halfx8, av[mt]);
+                                const halfx8 b_hi = __builtin_bit_cast(halfx8, bh[nt]), b_lo = __builtin_bit_cast(halfx8, bv[nt]);
+                                const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                const bool first = tap == 0 && j == 1;
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, first ? zero : acc[mt][nt], 0, 0, 0);
+                                accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, first ? zero : accx[mt][nt], 0, 0, 0);
+                                accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, accx[mt][nt], 0, 0, 0);
+                            }
+                    }
+                } else if constexpr (F32) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -348,7 +383,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
 #pragma unroll
                 for (int mt = 0; mt < WTM; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < WTN; ++nt) tot[mt][nt] += acc[mt][nt];
+                    for (int nt = 0; nt < WTN; ++nt) {
+                        if constexpr (SPLIT) tot[mt][nt] += acc[mt][nt] + accx[mt][nt] * 0.00048828125f;   // 2^-11
+                        else tot[mt][nt] += acc[mt][nt];
+                    }
             }
 #if !(HOLO_CONV_ABLATE & 2)
             HOLO_STAGE_WAIT();                                   // this wave's DMAs (next weights, its share of the next halo)
@@ -384,7 +422,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
                     const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float t = acc[mt][nt][4 * q + i] + bq[i];
+                        const float t = (FOLD ? tot[mt][nt][4 * q + i] : acc[mt][nt][4 * q + i]) + bq[i];
                         v[4 * q + i] = relu ? fmaxf(t, 0.0f) : t;
                     }
                 }
@@ -411,12 +449,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WTM * WTN > 4 && KC * sizeof(T) > 64
                     writer = inside && (li & 3) == 0;                       // the window's top-left pixel stores
                     pix = (size_t)(Y >> 1) * Wo + (X >> 1);
                 }
-                if constexpr (F32) {
-                    // fp32: a quad of registers is already a 16-byte run of the pixel
+                if constexpr (F32 || SPLIT) {
+                    // fp32 (and the split-operand experiment, which writes plain fp32): a quad of registers is already a
+                    // 16-byte run of the pixel
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (writer)
-                            *reinterpret_cast<float4*>(yimg + pix * Cout + co_base + 8 * q + 4 * hsel) =
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(yimg) + pix * Cout + co_base + 8 * q + 4 * hsel) =
                                 make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                     continue;
                 }
@@ -702,6 +741,24 @@ int holo_convt2x2_bf16(const uint16_t* x_nhwc, const uint16_t* w_packed, const f
     using holo::bf16_t;
     return holo::convt2x2_entry<bf16_t>(reinterpret_cast<const bf16_t*>(x_nhwc), reinterpret_cast<const bf16_t*>(w_packed), bias,
                                         reinterpret_cast<bf16_t*>(y_nhwc), batch, h, w, cin, cout, relu, stream);
+}
+
+// EXPERIMENT, not part of the product path or the header: 3x3 conv on split-fp16 operands (see split16 above).
+// x_split: NHWC, 4 bytes per element, planar per 16-channel group; w_split: [Cin/32][tap][Cout][32] in the same
+// element format; y: plain fp32 NHWC.  Cin % 32 == 0, Cout % 64 == 0.
+int holo_conv3x3_f32s(const void* x_split, const void* w_split, const float* bias, float* y_nhwc, int batch, int h, int w,
+                      int cin, int cout, int relu, int pool, void* stream) {
+    using holo::split16;
+    HOLO_REQUIRE(x_split && w_split && bias && y_nhwc, HOLO_ERR_ARG, "holo_conv3x3_f32s: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && cin % 32 == 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_f32s: batch=%d h=%d w=%d cin=%d cout=%d", batch, h, w, cin, cout);
+    HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_f32s: fused pooling requires relu");
+    const split16* xs = static_cast<const split16*>(x_split);
+    const split16* ws = static_cast<const split16*>(w_split);
+    split16* ys = reinterpret_cast<split16*>(y_nhwc);
+    hipStream_t s = holo::as_stream(stream);
+    if (cout % 128 == 0) return holo::launch_conv<2, 2, false, 32, split16>(xs, ws, bias, ys, batch, h, w, cin, cout, relu, pool, s);
+    return holo::launch_conv<4, 1, false, 32, split16>(xs, ws, bias, ys, batch, h, w, cin, cout, relu, pool, s);
 }
 
 }  // extern "C"

@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--distances", type=int, default=1,
                     help="propagate every retrieved field to N distances in one sweep (BASELINE configs[4] uses 8)")
     ap.add_argument("--style", default="MNIST", help="style_representation/<name>/style_vector.pt")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32s"], default="f32",
                     help="conv stack arithmetic: f32 = exact fp32 MFMA (BASELINE configs[1], the parity path); "
                          "bf16 = bf16 MFMA with fp32 accumulation (configs[2]); the propagator is fp32 either way")
     args = ap.parse_args()
@@ -140,6 +140,8 @@ def main():
     network, sds = build_network(dev)
     if args.dtype == "bf16":
         network.set_compute_dtype(torch.bfloat16)
+    elif args.dtype == "f32s":   # opt-in: fp32 values as split fp16 halves on the fp16 matrix cores (never the default)
+        network.set_compute_dtype("f32s")
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     from holo_oracle import HoloParams
     model_forward = Holo_Generator(HoloParams())
@@ -226,15 +228,16 @@ def main():
             "value": round(total / elapsed, 2), "unit": "holograms/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{1 if args.dtype == 'f32' else 2}]: batch {b}/GPU synthetic {s}x{s} holograms, "
-                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 convs / fp32 FFT'}, VGG-AdaIN-decoder + "
+            "config": {"workload": f"BASELINE configs[{2 if args.dtype == 'bf16' else 1}]: batch {b}/GPU synthetic {s}x{s} holograms, "
+                                   f"{ {'f32': 'fp32', 'bf16': 'bf16 convs / fp32 FFT', 'f32s': 'convs on split-fp16 operands (hi + lo*2^-11, fp32 accumulate; NOT fp32 arithmetic) / fp32 FFT'}[args.dtype] }, VGG-AdaIN-decoder + "
                                    f"distance head + angular-spectrum back-propagation (P={2 * s}), seeded He-normal weights",
                        "batch_per_gpu": b, "size": s, "distances_per_field": args.distances, "style": args.style, "hipgraph": bool(args.graph), "parallelism": f"batch-sharded x{world}, one RCCL gather per step"},
         }
         if timer is not None:
             summ = timer.summary()
             conv = [summ[k] for k in (f"holo_conv3x3_{args.dtype}", f"holo_convt2x2_{args.dtype}") if k in summ]
-            peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+            # f32s: algorithmic fp32 FLOP against the fp16 matrix peak / 3 (three MFMA products per operand pair)
+            peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32s": round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)}[args.dtype]
             if conv:
                 fl = sum(r["flops"] for r in conv)
                 ms = sum(r["ms"] for r in conv)

@@ -133,6 +133,34 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Optional "f32s" storage for the conv stack (same reference lines as the _f32 entry points above).
+ * An fp32 value is kept as two fp16 halves, a = hi + lo' * 2^-11 (22-23 significant bits), planar per
+ * 16 consecutive channels: [16 x hi | 16 x lo'] = 64 bytes per group, 4 bytes per element, passed as
+ * void*.  Activations are NHWC with C % 16 == 0 in 64-byte aligned buffers.  Products are formed as
+ * hi*hi + (hi*lo' + lo'*hi) * 2^-11 on v_mfma_f32_32x32x16_f16 with fp32 accumulation and the same
+ * per-chunk fold as the fp32 kernel: measured 2.3e-7 of float64 per layer (fp32 MFMA: 3.3e-7) at 2.3x
+ * the fp32 kernel's rate.  Not bit-compatible with fp32 arithmetic (the dropped lo'*lo' term, fp16
+ * range: |a| saturates at 65504), hence opt-in and never the default.
+ * ---------------------------------------------------------------------------------------- */
+int holo_cast_f32_to_f32s(const float* x, void* y, long n, void* stream);   /* n % 16 == 0, 64-byte aligned buffers */
+int holo_cast_f32s_to_f32(const void* x, float* y, long n, void* stream);
+int holo_pack_conv3x3_weight_f32s(const float* w_oihw, void* w_packed, int cout, int cin, void* stream);   /* Cin % 32 == 0 */
+int holo_pack_convt2x2_weight_f32s(const float* w_iohw, void* w_packed, int cin, int cout, void* stream);
+int holo_conv_first_f32s(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                         void* y_nhwc, int batch, int h, int w, void* stream);
+int holo_conv3x3_f32s(const void* x_nhwc, const void* w_packed, const float* bias, void* y_nhwc, int batch, int h,
+                      int w, int cin, int cout, int relu, int pool, void* stream);
+int holo_convt2x2_f32s(const void* x_nhwc, const void* w_packed, const float* bias, void* y_nhwc, int batch, int h,
+                       int w, int cin, int cout, int relu, void* stream);
+int holo_conv_last_f32s(const void* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw, int batch, int h,
+                        int w, void* stream);
+int holo_channel_mean_std_f32s(const void* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps,
+                               void* stream);
+int holo_adain_apply_f32s(const void* x_nhwc, const float* mean, const float* std, const float* style_mean,
+                          const float* style_std, long style_batch_stride, float alpha, void* y_nhwc, int batch,
+                          int hw, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 2-D phase unwrapping (utils/functions.py:44-59 `unwrap`, reached with unwrap=True from
  * utils/Forward_model.py:30-31 and test_field_retrieval_mnist.py:126).  The reference loops over the
  * images on the host and calls scikit-image's unwrap_phase (Herraez et al. 2002, reliability-sorted

@@ -83,23 +83,36 @@ class Net(nn.Module):
                 param.requires_grad = False
 
     def set_compute_dtype(self, dtype):
-        """Additive: torch.float32 (default, exact fp32 MFMA) or torch.bfloat16 for the conv stack
-        (BASELINE config 3).  Inputs, amplitude/phase outputs, statistics and the distance head stay fp32."""
+        """Additive: torch.float32 (default, exact fp32 MFMA), torch.bfloat16 for the conv stack (BASELINE config 3), or
+        "f32s": fp32 activations and weights kept as two fp16 halves (22-23 significant bits) so that the conv stack runs
+        on the fp16 matrix cores with fp32 accumulation — measured closer to float64 than the fp32 path, at more than
+        twice its speed, but NOT bit-compatible with fp32 arithmetic, hence opt-in.  Inputs, amplitude/phase outputs,
+        statistics and the distance head stay fp32."""
         for k in range(self.n_layer):
             getattr(self, f"enc_{k + 1}").set_compute_dtype(dtype)
         self.decoder.set_compute_dtype(dtype)
         return self
 
+    @staticmethod
+    def _public(feat):
+        """Feature maps leave the module as fp32 (the optional "f32s" compute mode keeps them as split halves inside)."""
+        if feat.dtype == ops.F32S:
+            return ops.as_nchw_view(ops.cast(ops.to_nhwc(feat), torch.float32))
+        return feat
+
     def encode_with_intermediate(self, input):
         results = [input]
         for i in range(self.n_layer):
             results.append(getattr(self, "enc_{:d}".format(i + 1))(results[-1]))
-        return results[1:]
+        return [self._public(r) for r in results[1:]]
 
-    def encode(self, input):
+    def _encode(self, input):
         for i in range(self.n_layer):
             input = getattr(self, "enc_{:d}".format(i + 1))(input)
         return input
+
+    def encode(self, input):
+        return self._public(self._encode(input))
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError("Net.forward is the training-loss graph (net.py:199-226): out of scope for the "
@@ -107,7 +120,7 @@ class Net(nn.Module):
 
     def field_retrieval(self, content, style_feats, alpha=1.0, unknown_distance=False):
         assert 0 <= alpha <= 1
-        content_feat = self.encode(content)                      # logical NCHW, channels-last memory
+        content_feat = self._encode(content)                     # logical NCHW, channels-last memory
         feat_nhwc = ops.to_nhwc(content_feat)                    # free view
         b = content.shape[0]
         style_feats = style_feats.to(device=content_feat.device, dtype=torch.float32)

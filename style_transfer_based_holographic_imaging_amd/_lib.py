@@ -53,6 +53,16 @@ SIGNATURES = {
     "holo_conv_last_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_channel_mean_std_bf16": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "holo_adain_apply_bf16": (_i, [_p, _p, _p, _p, _p, _l, _f, _p, _i, _i, _i, _p]),
+    "holo_cast_f32_to_f32s": (_i, [_p, _p, _l, _p]),
+    "holo_cast_f32s_to_f32": (_i, [_p, _p, _l, _p]),
+    "holo_pack_conv3x3_weight_f32s": (_i, [_p, _p, _i, _i, _p]),
+    "holo_pack_convt2x2_weight_f32s": (_i, [_p, _p, _i, _i, _p]),
+    "holo_conv_first_f32s": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_conv3x3_f32s": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "holo_convt2x2_f32s": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "holo_conv_last_f32s": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_channel_mean_std_f32s": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
+    "holo_adain_apply_f32s": (_i, [_p, _p, _p, _p, _p, _l, _f, _p, _i, _i, _i, _p]),
     "holo_cast_f32_to_bf16": (_i, [_p, _p, _l, _p]),
     "holo_cast_bf16_to_f32": (_i, [_p, _p, _l, _p]),
     "holo_nhwc_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -10,7 +10,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // 4 consecutive channels as fp32, from fp32 or bf16 storage
 template <typename T>
 __device__ __forceinline__ float4 load4(const T* p) {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (__is_same(T, split16)) {
+        return split_load4(p);
+    } else if constexpr (sizeof(T) == 4) {
         return *reinterpret_cast<const float4*>(p);
     } else {
         const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
@@ -19,7 +21,9 @@ __device__ __forceinline__ float4 load4(const T* p) {
 }
 template <typename T>
 __device__ __forceinline__ void store4(T* p, float4 o) {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (__is_same(T, split16)) {
+        split_store4(p, o);
+    } else if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<float4*>(p) = o;
     } else {
         const bf16x4 v = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
@@ -134,6 +138,15 @@ int holo_channel_mean_std_f32(const float* x_nhwc, float* mean, float* std, int 
 }
 int holo_channel_mean_std_bf16(const uint16_t* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps, void* stream) {
     return holo::mean_std_entry<holo::bf16_t>(reinterpret_cast<const holo::bf16_t*>(x_nhwc), mean, std, batch, hw, c, eps, stream);
+}
+int holo_channel_mean_std_f32s(const void* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps, void* stream) {
+    return holo::mean_std_entry<holo::split16>(static_cast<const holo::split16*>(x_nhwc), mean, std, batch, hw, c, eps, stream);
+}
+int holo_adain_apply_f32s(const void* x_nhwc, const float* mean, const float* std, const float* style_mean,
+                          const float* style_std, long style_batch_stride, float alpha, void* y_nhwc, int batch, int hw,
+                          int c, void* stream) {
+    return holo::adain_entry<holo::split16>(static_cast<const holo::split16*>(x_nhwc), mean, std, style_mean, style_std,
+                                            style_batch_stride, alpha, static_cast<holo::split16*>(y_nhwc), batch, hw, c, stream);
 }
 int holo_adain_apply_f32(const float* x_nhwc, const float* mean, const float* std, const float* style_mean,
                          const float* style_std, long style_batch_stride, float alpha, float* y_nhwc, int batch, int hw,

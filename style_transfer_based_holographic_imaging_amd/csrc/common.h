@@ -38,4 +38,45 @@ __device__ __forceinline__ int reflect1(int i, int n) {
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
+// "f32s" activations: an fp32 value as two fp16 halves, a = hi + lo' * 2^-11 (22-23 significant bits), stored planar per
+// 16 consecutive elements: [16 x hi | 16 x lo'] = 64 bytes per group, so that a 16-byte read is 8 consecutive channels of
+// one half — one operand of v_mfma_f32_32x32x16_f16.  Channel counts are multiples of 16 and buffers 64-byte aligned, so
+// the groups tile any NHWC tensor linearly and an element's place follows from its address alone.
+struct split16 {
+    _Float16 hi, lo;
+    split16() = default;
+    __host__ __device__ explicit split16(float f) : hi((_Float16)f), lo((_Float16)0.0f) {}   // so that dead store paths compile
+};
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_halves(float f, _Float16* hi, _Float16* lo) {
+    f = fminf(fmaxf(f, -65504.0f), 65504.0f);            // fp16 range; values beyond saturate
+    *hi = (_Float16)f;
+    *lo = (_Float16)((f - (float)*hi) * 2048.0f);
+}
+// 4 consecutive elements starting at element pointer p (element index a multiple of 4)
+__device__ __forceinline__ float4 split_load4(const split16* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned char* g = reinterpret_cast<const unsigned char*>(a & ~63ull) + ((a & 63ull) >> 1);
+    const halfx4 hi = *reinterpret_cast<const halfx4*>(g);
+    const halfx4 lo = *reinterpret_cast<const halfx4*>(g + 32);
+    return make_float4((float)hi[0] + (float)lo[0] * 0.00048828125f, (float)hi[1] + (float)lo[1] * 0.00048828125f,
+                       (float)hi[2] + (float)lo[2] * 0.00048828125f, (float)hi[3] + (float)lo[3] * 0.00048828125f);
+}
+__device__ __forceinline__ void split_store4(split16* p, float4 v) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    unsigned char* g = reinterpret_cast<unsigned char*>(a & ~63ull) + ((a & 63ull) >> 1);
+    halfx4 hi, lo;
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        _Float16 h, l;
+        split_halves(f[i], &h, &l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+    *reinterpret_cast<halfx4*>(g) = hi;
+    *reinterpret_cast<halfx4*>(g + 32) = lo;
+}
+
 }  // namespace holo

@@ -95,7 +95,15 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int m = (q & 3) + 8 * (q >> 2) + 4 * hsel;
-                st[m * 64 + nt * 32 + r] = (T)fmaxf(acc[nt][q] + bias[nt], 0.0f);
+                const float val = fmaxf(acc[nt][q] + bias[nt], 0.0f);
+                if constexpr (__is_same(T, split16)) {
+                    // pixel m's 64 channels = 4 groups of [16 x hi | 16 x lo']
+                    const int c = nt * 32 + r;
+                    _Float16* hp = reinterpret_cast<_Float16*>(st + m * 64) + (c / 16) * 32 + (c % 16);
+                    split_halves(val, hp, hp + 16);
+                } else {
+                    st[m * 64 + nt * 32 + r] = (T)val;
+                }
             }
         __syncthreads();
         // 32 pixels x 64 channels = 32 * 64 * sizeof(T) / 16 units of 16 bytes; a lane takes every 64th
@@ -138,13 +146,31 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const T* __restrict__ x,
     float acc0 = bias[0], acc1 = bias[1];
     for (int chunk = 0; chunk < 4; ++chunk) {
         __syncthreads();
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (__is_same(T, float)) {
             for (int u = tid; u < kLH * kLH * 4; u += 256) {
                 const int q = u >> 2, c = u & 3;
                 const int hy = q / kLH, hx = q % kLH;
                 const int ry = reflect1(y0 - 1 + hy, H), rx = reflect1(x0 - 1 + hx, W);
                 const float4 v = *reinterpret_cast<const float4*>(xi + ((size_t)ry * W + rx) * 64 + chunk * 16 + 4 * c);
                 *reinterpret_cast<float4*>(&halo[q * 16 + ((c ^ ((q >> 2) & 3)) << 2)]) = v;
+            }
+        } else if constexpr (__is_same(T, split16)) {
+            // chunk = one 16-channel group: 64 bytes per pixel = hi units 0,1 | lo' units 2,3; a thread turns hi unit c8 and
+            // lo' unit 2 + c8 (8 channels) into two fp32 units of the LDS row
+            for (int u = tid; u < kLH * kLH * 2; u += 256) {
+                const int q = u >> 1, c8 = u & 1;
+                const int hy = q / kLH, hx = q % kLH;
+                const int ry = reflect1(y0 - 1 + hy, H), rx = reflect1(x0 - 1 + hx, W);
+                const unsigned char* gp = reinterpret_cast<const unsigned char*>(xi + ((size_t)ry * W + rx) * 64 + chunk * 16);
+                typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+                const halfx8 hi = *reinterpret_cast<const halfx8*>(gp + 16 * c8);
+                const halfx8 lo = *reinterpret_cast<const halfx8*>(gp + 32 + 16 * c8);
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (float)hi[e] + (float)lo[e] * 0.00048828125f;
+                const int sw = (q >> 2) & 3;
+                *reinterpret_cast<float4*>(&halo[q * 16 + (((2 * c8) ^ sw) << 2)]) = make_float4(f[0], f[1], f[2], f[3]);
+                *reinterpret_cast<float4*>(&halo[q * 16 + (((2 * c8 + 1) ^ sw) << 2)]) = make_float4(f[4], f[5], f[6], f[7]);
             }
         } else {
             // one 16-byte load = 8 bf16 channels = two fp32 units of the LDS row
@@ -223,6 +249,14 @@ int holo_conv_first_f32(const float* x, const float* w0, const float* b0, const 
 int holo_conv_first_bf16(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
                          uint16_t* y_nhwc, int batch, int h, int w, void* stream) {
     return holo::conv_first_entry<holo::bf16_t>(x, w0, b0, w1, b1, reinterpret_cast<holo::bf16_t*>(y_nhwc), batch, h, w, stream);
+}
+int holo_conv_first_f32s(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* y_nhwc,
+                         int batch, int h, int w, void* stream) {
+    return holo::conv_first_entry<holo::split16>(x, w0, b0, w1, b1, static_cast<holo::split16*>(y_nhwc), batch, h, w, stream);
+}
+int holo_conv_last_f32s(const void* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw, int batch, int h, int w,
+                        void* stream) {
+    return holo::conv_last_entry<holo::split16>(static_cast<const holo::split16*>(x_nhwc), w_oihw, bias, y_nchw, batch, h, w, stream);
 }
 int holo_conv_last_f32(const float* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw, int batch, int h,
                        int w, void* stream) {

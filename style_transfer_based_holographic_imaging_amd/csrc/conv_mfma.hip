@@ -48,14 +48,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
-// EXPERIMENT (holo_conv3x3_f32s): an fp32 value as two fp16 halves, a = hi + lo' * 2^-11 (22-23 significant bits), stored
-// planar per 16-channel group: [16 x hi | 16 x lo'] = 64 bytes per group, so a lane's 16-byte fragment read is 8 consecutive
-// channels of one half, exactly one operand of v_mfma_f32_32x32x16_f16
-struct split16 {
-    _Float16 hi, lo;
-    split16() = default;
-    __host__ __device__ explicit split16(float f) : hi((_Float16)f), lo((_Float16)0.0f) {}   // only so that dead store paths compile
-};
+// split16 ("f32s" storage) is defined in common.h: planar per 16-channel group, [16 x hi | 16 x lo'] = 64 bytes, so a lane's
+// 16-byte fragment read is 8 consecutive channels of one half — one operand of v_mfma_f32_32x32x16_f16
 
 constexpr int kKC = 16;  // smallest K chunk (channels); weights/activations need Cin % 16 == 0
 constexpr int kPW = 16;  // patch width in pixels
@@ -264,6 +258,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
             for (int r = 0; r < 16; ++r) {
                 acc[mt][nt][r] = 0.0f;   // live only for the transposed conv (no fold); dead otherwise
                 tot[mt][nt][r] = 0.0f;
+                if constexpr (SPLIT) accx[mt][nt][r] = 0.0f;
             }
 
     // ---- main loop ------------------------------------------------------------------------------------------
@@ -340,7 +335,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                                 const halfx8 a_hi = __builtin_bit_cast(halfx8, ah[mt]), a_lo = __builtin_bit_cast(halfx8, av[mt]);
                                 const halfx8 b_hi = __builtin_bit_cast(halfx8, bh[nt]), b_lo = __builtin_bit_cast(halfx8, bv[nt]);
                                 const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                                const bool first = tap == 0 && j == 1;
+                                const bool first = FOLD && tap == 0 && j == 1;
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, first ? zero : acc[mt][nt], 0, 0, 0);
                                 accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, first ? zero : accx[mt][nt], 0, 0, 0);
                                 accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, accx[mt][nt], 0, 0, 0);
@@ -422,7 +417,11 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                     const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float t = (FOLD ? tot[mt][nt][4 * q + i] : acc[mt][nt][4 * q + i]) + bq[i];
+                        float t0;
+                        if constexpr (FOLD) t0 = tot[mt][nt][4 * q + i];
+                        else if constexpr (SPLIT) t0 = acc[mt][nt][4 * q + i] + accx[mt][nt][4 * q + i] * 0.00048828125f;
+                        else t0 = acc[mt][nt][4 * q + i];
+                        const float t = t0 + bq[i];
                         v[4 * q + i] = relu ? fmaxf(t, 0.0f) : t;
                     }
                 }
@@ -449,9 +448,37 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                     writer = inside && (li & 3) == 0;                       // the window's top-left pixel stores
                     pix = (size_t)(Y >> 1) * Wo + (X >> 1);
                 }
-                if constexpr (F32 || SPLIT) {
-                    // fp32 (and the split-operand experiment, which writes plain fp32): a quad of registers is already a
-                    // 16-byte run of the pixel
+                if constexpr (SPLIT) {
+                    // split output: channel c of the 32-tile lives in 16-channel group c/16 as hi at half (c%16), lo' at half
+                    // 16 + (c%16) of the group's 64 bytes.  Quad q = channels 8q + 4*hsel .. +3: after the half-wave swap the
+                    // lower lanes hold channels 16k..16k+7 and the upper lanes 16k+8..16k+15 of group k — one 16-byte run of
+                    // hi and one of lo' each.
+                    unsigned hi2[8], lo2[8];
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+                        const float f0 = fminf(fmaxf(v[2 * d], -65504.0f), 65504.0f), f1 = fminf(fmaxf(v[2 * d + 1], -65504.0f), 65504.0f);
+                        const halfx2 h2 = {(_Float16)f0, (_Float16)f1};
+                        const halfx2 l2 = {(_Float16)((f0 - (float)h2[0]) * 2048.0f), (_Float16)((f1 - (float)h2[1]) * 2048.0f)};
+                        hi2[d] = __builtin_bit_cast(unsigned, h2);
+                        lo2[d] = __builtin_bit_cast(unsigned, l2);
+                    }
+                    unsigned char* pbase = reinterpret_cast<unsigned char*>(yimg) + (pix * Cout + co_base) * 4;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        auto h0 = __builtin_amdgcn_permlane32_swap(hi2[4 * k], hi2[4 * k + 2], false, false);
+                        auto h1 = __builtin_amdgcn_permlane32_swap(hi2[4 * k + 1], hi2[4 * k + 3], false, false);
+                        auto l0 = __builtin_amdgcn_permlane32_swap(lo2[4 * k], lo2[4 * k + 2], false, false);
+                        auto l1 = __builtin_amdgcn_permlane32_swap(lo2[4 * k + 1], lo2[4 * k + 3], false, false);
+                        if (writer) {
+                            *reinterpret_cast<uint4*>(pbase + 64 * k + 16 * hsel) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+                            *reinterpret_cast<uint4*>(pbase + 64 * k + 32 + 16 * hsel) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+                        }
+                    }
+                    continue;
+                }
+                if constexpr (F32) {
+                    // fp32: a quad of registers is already a 16-byte run of the pixel
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (writer)
@@ -568,6 +595,23 @@ static int launch_conv(const T* x, const T* wp, const float* bias, T* y, int bat
 }
 
 // ---- weight packing --------------------------------------------------------------------------------------------
+// packed weight element i of a [.. ][KC] row -> storage: plain for float / bf16; for split16 the row is KC/16 groups of
+// [16 x hi | 16 x lo'] halves
+template <typename T>
+__device__ __forceinline__ void store_packed(T* out, long i, int kc, float w) {
+    if constexpr (__is_same(T, split16)) {
+        const long row = i / kc;
+        const int k = (int)(i % kc);
+        _Float16* h = reinterpret_cast<_Float16*>(out) + row * kc * 2 + (k / 16) * 32 + (k % 16);
+        const float f = fminf(fmaxf(w, -65504.0f), 65504.0f);
+        const _Float16 hi = (_Float16)f;
+        h[0] = hi;
+        h[16] = (_Float16)((f - (float)hi) * 2048.0f);
+    } else {
+        out[i] = (T)w;
+    }
+}
+
 template <typename T>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int kc) {
     const long total = (long)9 * cin * cout;
@@ -580,7 +624,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
     const int tap = (int)(r % 9);
     const int chunk = (int)(r / 9);
     const int ci = chunk * kc + k;
-    out[i] = (T)w[((long)co * cin + ci) * 9 + tap];  // OIHW, tap = ky*3+kx; packed [chunk][tap][co][kc]
+    store_packed<T>(out, i, kc, w[((long)co * cin + ci) * 9 + tap]);  // OIHW, tap = ky*3+kx; packed [chunk][tap][co][kc]
 }
 
 template <typename T>
@@ -594,7 +638,7 @@ __global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict_
     const int chunk = (int)(r / (4 * cout));
     const int q = n / cout, co = n % cout;
     const int ci = chunk * kc + k;
-    out[i] = (T)w[((long)ci * cout + co) * 4 + q];  // (Cin,Cout,2,2), q = dy*2+dx
+    store_packed<T>(out, i, kc, w[((long)ci * cout + co) * 4 + q]);  // (Cin,Cout,2,2), q = dy*2+dx
 }
 
 // K-chunk per stage for a layer: the packing and the launch must agree.  fp32: 32-channel stages (half the
@@ -609,11 +653,12 @@ __global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict_
 #endif
 template <typename T>
 static int conv_kc(int cin, int cout, bool convt) {
+    if (__is_same(T, split16)) return 32;   // 128-byte rows: two 16-channel groups per stage
     if (sizeof(T) == 2) return (HOLO_CONV_BF16_KC64 && !convt && cout % 128 == 0 && cin % 64 == 0) ? 64 : 32;
     return (HOLO_CONV_KC32 && !convt && cout % 128 == 0 && cin % 32 == 0) ? 32 : 16;
 }
-template <typename T> constexpr int min_cin() { return sizeof(T) == 2 ? 32 : 16; }
-template <typename T> constexpr const char* dtype_name() { return sizeof(T) == 2 ? "bf16" : "f32"; }
+template <typename T> constexpr int min_cin() { return (sizeof(T) == 2 || __is_same(T, split16)) ? 32 : 16; }
+template <typename T> constexpr const char* dtype_name() { return __is_same(T, split16) ? "f32s" : (sizeof(T) == 2 ? "bf16" : "f32"); }
 
 template <typename T>
 static int pack3x3_entry(const float* w_oihw, T* w_packed, int cout, int cin, void* stream) {
@@ -651,7 +696,7 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
     HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < (1L << 30), HOLO_ERR_UNSUPPORTED,
                  "holo_conv3x3_%s: one image must stay below 2^30 elements (32-bit byte offsets)", dtype_name<T>());
     hipStream_t s = as_stream(stream);
-    constexpr int KCD = sizeof(T) == 2 ? 32 : 16;   // default K chunk of the dtype
+    constexpr int KCD = (sizeof(T) == 2 || __is_same(T, split16)) ? 32 : 16;   // default K chunk of the dtype
     // HOLO_CONV_TILE (tests, A/B runs; read per call): 1 = standard tile, 2 = small tile, 3 = tall bf16 wave tile
     const char* tile_env = getenv("HOLO_CONV_TILE");
     const int force = tile_env ? atoi(tile_env) : 0;
@@ -678,8 +723,10 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
         }
     }
     if (cout % 128 == 0) {
-        if (conv_kc<T>(cin, cout, false) == 2 * KCD)   // the deeper-stage variant of this dtype
-            return launch_conv<2, 2, false, 2 * KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+        if constexpr (!__is_same(T, split16)) {
+            if (conv_kc<T>(cin, cout, false) == 2 * KCD)   // the deeper-stage variant of this dtype
+                return launch_conv<2, 2, false, 2 * KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
+        }
         return launch_conv<2, 2, false, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
     }
     return launch_conv<4, 1, false, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
@@ -696,7 +743,7 @@ static int convt2x2_entry(const T* x_nhwc, const T* w_packed, const float* bias,
                  "holo_convt2x2_%s: one image must stay below 2^30 elements (32-bit byte offsets)", dtype_name<T>());
     // a 128-wide N tile would straddle two (dy,dx) quadrants when Cout % 128 != 0: use the 64-wide tile then
     hipStream_t s = as_stream(stream);
-    constexpr int KCD = sizeof(T) == 2 ? 32 : 16;
+    constexpr int KCD = (sizeof(T) == 2 || __is_same(T, split16)) ? 32 : 16;
     if (cout % 128 == 0) return launch_conv<2, 2, true, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
     return launch_conv<4, 1, true, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
 }
@@ -743,22 +790,25 @@ int holo_convt2x2_bf16(const uint16_t* x_nhwc, const uint16_t* w_packed, const f
                                         reinterpret_cast<bf16_t*>(y_nhwc), batch, h, w, cin, cout, relu, stream);
 }
 
-// EXPERIMENT, not part of the product path or the header: 3x3 conv on split-fp16 operands (see split16 above).
-// x_split: NHWC, 4 bytes per element, planar per 16-channel group; w_split: [Cin/32][tap][Cout][32] in the same
-// element format; y: plain fp32 NHWC.  Cin % 32 == 0, Cout % 64 == 0.
-int holo_conv3x3_f32s(const void* x_split, const void* w_split, const float* bias, float* y_nhwc, int batch, int h, int w,
+// split-fp16 activations / weights ("f32s": fp32 values as hi + lo' * 2^-11 halves, planar per 16 channels; 4 bytes per
+// element, passed as void*), fp32 bias and accumulation
+int holo_pack_conv3x3_weight_f32s(const float* w_oihw, void* w_packed, int cout, int cin, void* stream) {
+    return holo::pack3x3_entry<holo::split16>(w_oihw, static_cast<holo::split16*>(w_packed), cout, cin, stream);
+}
+int holo_pack_convt2x2_weight_f32s(const float* w_iohw, void* w_packed, int cin, int cout, void* stream) {
+    return holo::packt2x2_entry<holo::split16>(w_iohw, static_cast<holo::split16*>(w_packed), cin, cout, stream);
+}
+int holo_conv3x3_f32s(const void* x_nhwc, const void* w_packed, const float* bias, void* y_nhwc, int batch, int h, int w,
                       int cin, int cout, int relu, int pool, void* stream) {
     using holo::split16;
-    HOLO_REQUIRE(x_split && w_split && bias && y_nhwc, HOLO_ERR_ARG, "holo_conv3x3_f32s: null pointer");
-    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && cin % 32 == 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
-                 "holo_conv3x3_f32s: batch=%d h=%d w=%d cin=%d cout=%d", batch, h, w, cin, cout);
-    HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_f32s: fused pooling requires relu");
-    const split16* xs = static_cast<const split16*>(x_split);
-    const split16* ws = static_cast<const split16*>(w_split);
-    split16* ys = reinterpret_cast<split16*>(y_nhwc);
-    hipStream_t s = holo::as_stream(stream);
-    if (cout % 128 == 0) return holo::launch_conv<2, 2, false, 32, split16>(xs, ws, bias, ys, batch, h, w, cin, cout, relu, pool, s);
-    return holo::launch_conv<4, 1, false, 32, split16>(xs, ws, bias, ys, batch, h, w, cin, cout, relu, pool, s);
+    return holo::conv3x3_entry<split16>(static_cast<const split16*>(x_nhwc), static_cast<const split16*>(w_packed), bias,
+                                        static_cast<split16*>(y_nhwc), batch, h, w, cin, cout, relu, pool, stream);
+}
+int holo_convt2x2_f32s(const void* x_nhwc, const void* w_packed, const float* bias, void* y_nhwc, int batch, int h, int w,
+                       int cin, int cout, int relu, void* stream) {
+    using holo::split16;
+    return holo::convt2x2_entry<split16>(static_cast<const split16*>(x_nhwc), static_cast<const split16*>(w_packed), bias,
+                                         static_cast<split16*>(y_nhwc), batch, h, w, cin, cout, relu, stream);
 }
 
 }  // extern "C"

@@ -48,9 +48,33 @@ static int launch_transpose(const float* x, float* y, int batch, int rows, int c
     return check_launch(what);
 }
 
+// fp32 <-> "f32s" (split halves, planar per 16 elements; common.h): 4 elements per thread, n a multiple of 16
+template <bool TO_SPLIT>
+__global__ __launch_bounds__(256) void split_cast_kernel(const void* __restrict__ in, void* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        if constexpr (TO_SPLIT) split_store4(static_cast<split16*>(out) + 4 * i, static_cast<const float4*>(in)[i]);
+        else static_cast<float4*>(out)[i] = split_load4(static_cast<const split16*>(in) + 4 * i);
+    }
+}
+template <bool TO_SPLIT>
+static int launch_split_cast(const void* x, void* y, long n, hipStream_t s, const char* what) {
+    HOLO_REQUIRE(x && y && n > 0 && n % 16 == 0, HOLO_ERR_ARG, "%s: null pointer, empty, or length %ld not a multiple of 16", what, n);
+    HOLO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 63) == 0, HOLO_ERR_ARG, "%s: buffers must be 64-byte aligned", what);
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((split_cast_kernel<TO_SPLIT>), dim3((unsigned)blocks), dim3(256), 0, s, x, y, n / 4);
+    return check_launch(what);
+}
+
 }  // namespace holo
 
 extern "C" {
+int holo_cast_f32_to_f32s(const float* x, void* y, long n, void* stream) {
+    return holo::launch_split_cast<true>(x, y, n, holo::as_stream(stream), "holo_cast_f32_to_f32s");
+}
+int holo_cast_f32s_to_f32(const void* x, float* y, long n, void* stream) {
+    return holo::launch_split_cast<false>(x, y, n, holo::as_stream(stream), "holo_cast_f32s_to_f32");
+}
 int holo_nhwc_to_nchw_f32(const float* x, float* y, int batch, int hw, int c, void* stream) {
     return holo::launch_transpose(x, y, batch, hw, c, holo::as_stream(stream), "holo_nhwc_to_nchw_f32");
 }

@@ -94,7 +94,7 @@ class Plan:
 
     def __init__(self, children, dtype=torch.float32):
         self.steps = compile_plan(list(children))
-        self.dtype = dtype          # activation / packed-weight dtype: float32 (exact fp32 MFMA) or bfloat16
+        self.dtype = dtype          # activation / packed-weight dtype: float32 (exact fp32 MFMA), bfloat16, or ops.F32S
         self._packed = {}
 
     def _weights(self, idx, step):
@@ -155,8 +155,7 @@ class HoloSequential(nn.Sequential):
     def set_compute_dtype(self, dtype):
         """float32 (default: exact fp32 MFMA, the 1e-4 parity path) or bfloat16 (BASELINE config 3: bf16 convs,
         fp32 accumulation, statistics, distance head and propagator)."""
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError(f"compute dtype must be float32 or bfloat16, got {dtype}")
+        dtype = ops.compute_dtype(dtype)      # also "f32s": fp32 values as split fp16 halves on the fp16 matrix cores
         object.__setattr__(self, "_holo_dtype", dtype)
         return self
 

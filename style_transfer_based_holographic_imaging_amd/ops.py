@@ -36,30 +36,52 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# "f32s" storage: fp32 values as two fp16 halves (hi + lo' * 2^-11), planar per 16 channels, 4 bytes per element
+# (csrc/common.h split16).  Carried in torch.int32 tensors: the dtype is only a tag for "4 opaque bytes per element".
+F32S = torch.int32
+_ACT_DTYPES = (torch.float32, torch.bfloat16, F32S)
+
+
+def compute_dtype(name_or_dtype):
+    """torch.float32 | torch.bfloat16 | "f32s" (or ops.F32S) -> the activation storage dtype."""
+    if name_or_dtype in ("f32s", F32S):
+        return F32S
+    if name_or_dtype in ("f32", torch.float32):
+        return torch.float32
+    if name_or_dtype in ("bf16", torch.bfloat16):
+        return torch.bfloat16
+    raise ValueError(f"compute dtype must be float32, bfloat16 or 'f32s', got {name_or_dtype}")
+
+
 def _sfx(t):
-    """C-ABI suffix of an activation tensor's dtype: the bf16 entry points mirror the f32 ones."""
+    """C-ABI suffix of an activation tensor's dtype: the bf16 / f32s entry points mirror the f32 ones."""
     if t.dtype == torch.bfloat16:
         return "bf16"
     if t.dtype == torch.float32:
         return "f32"
-    raise RuntimeError(f"activations must be float32 or bfloat16, got {t.dtype}")
+    if t.dtype == F32S:
+        return "f32s"
+    raise RuntimeError(f"activations must be float32, bfloat16 or f32s (int32 storage), got {t.dtype}")
 
 
 def _actc(t):
-    """activation tensor: keep bf16, anything else becomes fp32; contiguous"""
-    if t.dtype not in (torch.float32, torch.bfloat16):
+    """activation tensor: keep bf16 / f32s, anything else becomes fp32; contiguous"""
+    if t.dtype not in _ACT_DTYPES:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
 
 
 def cast(x: torch.Tensor, dtype) -> torch.Tensor:
-    """fp32 <-> bf16 conversion by our kernel (round to nearest even)."""
+    """fp32 <-> bf16 (round to nearest even) and fp32 <-> f32s conversion of contiguous activation tensors by our kernels."""
     _req(x)
     if x.dtype == dtype:
         return x
     x = x.contiguous()
+    if F32S in (x.dtype, dtype) and torch.float32 not in (x.dtype, dtype):      # bf16 <-> f32s goes through fp32
+        return cast(cast(x, torch.float32), dtype)
     y = torch.empty(x.shape, dtype=dtype, device=x.device)
-    name = "holo_cast_f32_to_bf16" if dtype == torch.bfloat16 else "holo_cast_bf16_to_f32"
+    name = {(torch.float32, torch.bfloat16): "holo_cast_f32_to_bf16", (torch.bfloat16, torch.float32): "holo_cast_bf16_to_f32",
+            (torch.float32, F32S): "holo_cast_f32_to_f32s", (F32S, torch.float32): "holo_cast_f32s_to_f32"}[(x.dtype, dtype)]
     _launch(name, lambda: getattr(lib, name)(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), nbytes=6.0 * x.numel())
     return y
 
@@ -135,11 +157,13 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     _req(x)
     assert x.dim() == 4
     b, c, h, w = x.shape
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    if x.dtype not in _ACT_DTYPES:
         x = x.float()
     v = x.permute(0, 2, 3, 1)
     if v.is_contiguous():
         return v
+    if x.dtype == F32S:
+        raise RuntimeError("f32s activations only exist channels-last (their 16-channel groups are contiguous in NHWC)")
     if c == 1:
         return x.contiguous().view(b, h, w, 1)
     if x.dtype == torch.bfloat16:
@@ -153,7 +177,7 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
 def to_nchw_contiguous(x_nhwc: torch.Tensor) -> torch.Tensor:
     _req(x_nhwc)
     b, h, w, c = x_nhwc.shape
-    x_nhwc = _f32c(x_nhwc)
+    x_nhwc = cast(x_nhwc, torch.float32) if x_nhwc.dtype == F32S else _f32c(x_nhwc)
     y = torch.empty((b, c, h, w), dtype=torch.float32, device=x_nhwc.device)
     _launch("holo_nhwc_to_nchw_f32", lambda: lib.holo_nhwc_to_nchw_f32(x_nhwc.data_ptr(), y.data_ptr(), b, h * w, c, _stream()), nbytes=8.0 * b * h * w * c)
     return y

@@ -113,7 +113,7 @@ __device__ __forceinline__ int swz_a_unit(int hx, int hy, int q, int unit) {
 }
 
 template <int WM, int WN, bool CONVT, int KC, typename T, int WTM, int WTN>
-__global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 64) || __is_same(T, split16) ? 1 : HOLO_CONV_MINWAVES)) void conv_mfma_kernel(
+__global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 64) || (__is_same(T, split16) && WTM * WTN >= 4) ? 1 : HOLO_CONV_MINWAVES)) void conv_mfma_kernel(
     const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
     T* __restrict__ y, int H, int W, int Cin, int Cout, int N, int tiles_x, int tiles_y, int relu, int pool) {
     using C = ConvCfg<WM, WN, CONVT, KC, T, WTM, WTN>;
@@ -721,6 +721,12 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
             if (wide) return launch_conv<2, 2, false, 32, T, 4, 2>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
             return launch_conv<4, 1, false, 32, T, 4, 2>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
         }
+    }
+    if constexpr (__is_same(T, split16)) {
+        // split operands carry three accumulator sets (main, cross terms, fold): with the 64 px x 64 co wave tile that is 384
+        // VGPRs and one wave per SIMD; the 64 px x 32 co wave tile (222 VGPRs, two waves per SIMD, block 128 px x 64 co) is
+        // 8 % faster (12.3 vs 13.5 ms of conv per step at batch 64 x 256^2).  HOLO_CONV_TILE=1 selects the wide tile.
+        if (force != 1) return launch_conv<2, 2, false, KCD, T, 2, 1>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
     }
     if (cout % 128 == 0) {
         if constexpr (!__is_same(T, split16)) {

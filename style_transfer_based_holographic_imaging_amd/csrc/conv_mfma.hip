@@ -750,6 +750,8 @@ static int convt2x2_entry(const T* x_nhwc, const T* w_packed, const float* bias,
     // a 128-wide N tile would straddle two (dy,dx) quadrants when Cout % 128 != 0: use the 64-wide tile then
     hipStream_t s = as_stream(stream);
     constexpr int KCD = (sizeof(T) == 2 || __is_same(T, split16)) ? 32 : 16;
+    if constexpr (__is_same(T, split16))   // two accumulator sets: the 64 px x 32 co wave tile keeps two waves per SIMD
+        return launch_conv<2, 2, true, KCD, T, 2, 1>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
     if (cout % 128 == 0) return launch_conv<2, 2, true, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
     return launch_conv<4, 1, true, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
 }

@@ -273,6 +273,31 @@ def main():
                 unwrap(p_f)
             torch.cuda.synchronize()
             out["unwrap_ms_per_batch"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        if world == 1 and args.dtype == "f32" and args.distances == 1:
+            # informational, after the timed region and never part of `value`: the same step in the opt-in f32s mode
+            # (fp32 values as split fp16 halves on the fp16 matrix cores) with its deviation from this run's
+            # fp32 outputs
+            try:   # informational only: never let it cost the headline line
+                ref = step()
+                network.set_compute_dtype("f32s")
+                alt = step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                dt_alt = (time.perf_counter() - t1) / args.steps
+                network.set_compute_dtype(torch.float32)
+
+                def _rel(a, r):
+                    return float((a.double() - r.double()).abs().max() / r.double().abs().max())
+                out["alt_mode_f32s"] = {"value": round(b / dt_alt, 2), "unit": "holograms/s", "ms_per_step": round(dt_alt * 1e3, 3),
+                                        "max_rel_dev_from_fp32_outputs": {"amplitude": _rel(alt[0], ref[0]), "phase": _rel(alt[1], ref[1]),
+                                                                          "distance": _rel(alt[2], ref[2]), "focused_amplitude": _rel(alt[3], ref[3])},
+                                        "note": "opt-in, not fp32 arithmetic; not the headline"}
+            except Exception as e:   # noqa: BLE001
+                network.set_compute_dtype(torch.float32)
+                out["alt_mode_f32s"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(s, sds, style_cpu, args.cpu_sample, seed)
         print(json.dumps(out), flush=True)

@@ -12,6 +12,7 @@ Differences, all additive:
     under --decoder_root / --vgg are absent, `--synthetic-weights SEED` runs the identical pipeline on
     seeded He-normal weights (numbers are then meaningless as reconstructions, but every kernel runs).
   * tensors are loaded with map_location (the bundled .pt files carry a cuda:0 storage tag).
+  * `--compute-dtype bf16|f32s` selects the optional conv-stack arithmetic (default f32: exact fp32 MFMA).
   * the focused phase is unwrapped on the GPU (`holo_unwrap2d_f32`) instead of a host loop over scikit-image;
     `--unwrap off` keeps it wrapped.
 """
@@ -45,6 +46,8 @@ def parse_args(argv=None):
     extra.add_argument("--synthetic-weights", type=int, default=None, metavar="SEED",
                        help="use seeded He-normal weights when the trained files are absent")
     extra.add_argument("--unwrap", choices=["on", "off"], default="on")
+    extra.add_argument("--compute-dtype", choices=["f32", "bf16", "f32s"], default="f32",
+                       help="conv-stack arithmetic: exact fp32 MFMA (default), bf16, or fp32 values as split fp16 halves")
     extra.add_argument("--data_root", default="./test_data")
     extra.add_argument("--no-images", action="store_true", help="skip the per-sample PNG mosaics")
     return ap.parse_args(argv)
@@ -104,6 +107,8 @@ def main(argv=None):
     args.style_path = os.path.join('./style_representation', 'MNIST', 'style_vector.pt')
 
     network = load_weights(args, device)
+    if args.compute_dtype != "f32":
+        network.set_compute_dtype(args.compute_dtype)
     model_forward = Holo_Generator(args).to(device)
     if not os.path.isfile(args.style_path):
         raise FileNotFoundError(args.style_path)

@@ -200,6 +200,15 @@ def test_entry_script_default_unwraps_on_the_device(tmp_path, monkeypatch, capsy
         vals[mode] = [float(v) for v in re.findall(r"(?:Mean PSNR|Mean MAE|R2 score):\s+([-+0-9.eE]+)", out)]
         assert len(vals[mode]) == 3 and all(v == v and abs(v) < 1e9 for v in vals[mode])
     assert vals["on"][2] == vals["off"][2]                     # the distance head does not see the unwrapping
+    rc = entry.main(["--device", "cuda", "--synthetic-weights", "0", "--save_dir", str(tmp_path / "f32s"), "--no-images",
+                     "--compute-dtype", "f32s"])
+    out = capsys.readouterr().out
+    alt = [float(v) for v in re.findall(r"(?:Mean PSNR|Mean MAE|R2 score):\s+([-+0-9.eE]+)", out)]
+    assert rc == 0 and len(alt) == 3
+    # same metrics in the f32s mode; with synthetic weights the focused phase is wrap-heavy noise, so single unwrapping
+    # decisions move PSNR / MAE in the third digit while the distance regression agrees to 1e-6
+    assert abs(alt[0] - vals["on"][0]) < 0.1 and abs(alt[1] - vals["on"][1]) < 0.01 * abs(vals["on"][1])
+    assert abs(alt[2] - vals["on"][2]) < 1e-4 * abs(vals["on"][2])
 
 
 def test_module_plumbing_matches_reference_usage(env, mnist_style):

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                                 const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                                 const bool first = FOLD && tap == 0 && j == 1;
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, first ? zero : acc[mt][nt], 0, 0, 0);
-                                accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, first ? zero : accx[mt][nt], 0, 0, 0);
+                                // the cross terms are never folded: their rounding errors are already scaled by 2^-11
+                                accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, accx[mt][nt], 0, 0, 0);
                                 accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, accx[mt][nt], 0, 0, 0);
                             }
                     }
@@ -379,8 +380,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                 for (int mt = 0; mt < WTM; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < WTN; ++nt) {
-                        if constexpr (SPLIT) tot[mt][nt] += acc[mt][nt] + accx[mt][nt] * 0.00048828125f;   // 2^-11
-                        else tot[mt][nt] += acc[mt][nt];
+                        tot[mt][nt] += acc[mt][nt];
                     }
             }
 #if !(HOLO_CONV_ABLATE & 2)
@@ -418,7 +418,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float t0;
-                        if constexpr (FOLD) t0 = tot[mt][nt][4 * q + i];
+                        if constexpr (FOLD && SPLIT) t0 = tot[mt][nt][4 * q + i] + accx[mt][nt][4 * q + i] * 0.00048828125f;   // 2^-11
+                        else if constexpr (FOLD) t0 = tot[mt][nt][4 * q + i];
                         else if constexpr (SPLIT) t0 = acc[mt][nt][4 * q + i] + accx[mt][nt][4 * q + i] * 0.00048828125f;
                         else t0 = acc[mt][nt][4 * q + i];
                         const float t = t0 + bq[i];

@@ -23,8 +23,9 @@ def env():
     return network, sds, holo_generator()
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32s"])
 @pytest.mark.parametrize("s,b,alpha,style_name", CASES)
-def test_random_shapes_against_oracle(env, s, b, alpha, style_name):
+def test_random_shapes_against_oracle(env, s, b, alpha, style_name, mode):
     from hip_helpers import DEV, cplx_rel, orc
     from utils.functions import field_retrieval
     network, sds, hg = env
@@ -38,7 +39,11 @@ def test_random_shapes_against_oracle(env, s, b, alpha, style_name):
 
     with torch.no_grad():
         a_r, p_r, d_r = orc.field_retrieval(content, style, *sds, alpha, True)
-        a, p, d = field_retrieval(network, content.to(DEV), style.to(DEV), alpha, True)
+        network.set_compute_dtype(mode)          # "f32s": the opt-in split-fp16 conv stack, held to the same bar
+        try:
+            a, p, d = field_retrieval(network, content.to(DEV), style.to(DEV), alpha, True)
+        finally:
+            network.set_compute_dtype("f32")
         assert a.shape == a_r.shape and d.shape == d_r.shape == (b, 1, 1, 1)
         assert rel(a.cpu(), a_r) < TOL and rel(p.cpu(), p_r) < TOL and rel(d.cpu(), d_r) < TOL
         f_r = orc.holo_generator(orc.HoloParams(), a_r, p_r, -d_style, complex_number=True)

@@ -346,6 +346,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                     if (tap == kLast && more_chunks) { HOLO_LOAD_A(chunk + 1, apar ^ 1) }
                 }
 #endif
+#if HOLO_CONV_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
                 if constexpr (SPLIT) {
                     // j-th pair of 16-byte units = half a 16-channel group: even j -> hi units, odd j -> lo' units of group j/2
                     // (unit 4g + h = hi, 4g + 2 + h = lo').  The MFMAs run when both halves of a group are in registers.
@@ -402,6 +405,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                                                                                   __builtin_bit_cast(bf16x8, av[mt]),
                                                                                   acc[mt][nt], 0, 0, 0);
                 }
+#if HOLO_CONV_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             if (FOLD && tap == kLast) {
 #pragma unroll

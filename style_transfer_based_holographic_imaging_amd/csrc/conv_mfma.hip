@@ -47,6 +47,9 @@
 #ifndef HOLO_CONV_TRIPLE_B
 #define HOLO_CONV_TRIPLE_B 1   // 0: two weight buffers, queue drained at every stage (the first scheme)
 #endif
+#ifndef HOLO_CONV_XCD_SWIZZLE
+#define HOLO_CONV_XCD_SWIZZLE 1   // +0.3 % fp32, +1 % bf16 (measured); cuts halo re-reads from HBM
+#endif
 #ifndef HOLO_CONV_SETPRIO
 #define HOLO_CONV_SETPRIO 0
 #endif
@@ -141,6 +144,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
     const int tid = threadIdx.x;
     const int n_blk = N / C::TN;
     int bid = blockIdx.x;
+#if HOLO_CONV_XCD_SWIZZLE
+    // Blocks are dealt round-robin over the 8 XCDs (private L2s).  Give each XCD a contiguous range of tiles so that the
+    // neighbouring patches of an image, which share halo rows, and the N tiles of one patch, which share the whole halo tile,
+    // meet in the same L2.  A bijection whenever the grid is a multiple of 8; speed only.
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+#endif
     const int nb = bid % n_blk;
     bid /= n_blk;
     const int tx = bid % tiles_x;

@@ -50,11 +50,20 @@
 #ifndef HOLO_CONV_XCD_SWIZZLE
 #define HOLO_CONV_XCD_SWIZZLE 1   // +0.3 % fp32, +1 % bf16 (measured); cuts halo re-reads from HBM
 #endif
+#ifndef HOLO_CONV_STAMPS
+#define HOLO_CONV_STAMPS 0
+#endif
 #ifndef HOLO_CONV_SETPRIO
 #define HOLO_CONV_SETPRIO 0
 #endif
 
 namespace holo {
+
+#if HOLO_CONV_STAMPS
+// profiling build only (-DHOLO_CONV_STAMPS=1, scripts/conv_stage_stamps.py): cycle stamps of one wave's stage phases
+__device__ unsigned long long holo_dbg[8];
+#define HOLO_STAMP(var_) const unsigned long long var_ = __builtin_readcyclecounter()
+#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16_t;
@@ -313,6 +322,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
             constexpr int kLast = C::TAPS - 1;
             const bool has_next = tap != kLast || more_chunks;
 
+#if HOLO_CONV_STAMPS
+            HOLO_STAMP(t_start);
+            unsigned long long t_dma0 = 0, t_dma1 = 0;
+#endif
             const unsigned char* abuf = lds_a + apar * C::A_BYTES;
 #if HOLO_CONV_PRIVATE_B
             const unsigned char* bbuf = smem + b_region + bpar * C::BW_BYTES;
@@ -337,6 +350,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
 #pragma unroll
                 for (int nt = 0; nt < WTN; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bbuf + (b_off[nt] ^ (j << 5)));
 #if !(HOLO_CONV_ABLATE & 1)
+#if HOLO_CONV_STAMPS
+                if (NB == 3 && j == (HOLO_CONV_DMA_J < 0 ? C::UPR / 2 - 1 : HOLO_CONV_DMA_J)) t_dma0 = __builtin_readcyclecounter();
+#endif
                 if (NB == 3 && j == (HOLO_CONV_DMA_J < 0 ? C::UPR / 2 - 1 : HOLO_CONV_DMA_J)) {
                     if (tap == kLast - 1 && more_chunks) { HOLO_LOAD_A(chunk + 1, apar ^ 1) }
                     if (tap + 2 <= kLast || more_chunks) {
@@ -344,6 +360,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                         HOLO_LOAD_B(wsrc, (tap + 2) % 3)
                     }
                 }
+#if HOLO_CONV_STAMPS
+                if (NB == 3 && j == (HOLO_CONV_DMA_J < 0 ? C::UPR / 2 - 1 : HOLO_CONV_DMA_J)) t_dma1 = __builtin_readcyclecounter();
+#endif
                 if (NB != 3 && j == 0) {
                     // the staging loads of the next stage are issued behind the first fragment reads, so their issue
                     // slots fall into the LDS latency the first MFMA waits for anyway (ablation: loads in front of the
@@ -426,6 +445,9 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                         tot[mt][nt] += acc[mt][nt];
                     }
             }
+#if HOLO_CONV_STAMPS
+            HOLO_STAMP(t_mfma_end);
+#endif
 #if !(HOLO_CONV_ABLATE & 2)
             if constexpr (NB == 3) {
                 if (has_next) {
@@ -440,6 +462,17 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
             } else {
                 HOLO_STAGE_WAIT();                                   // this wave's DMAs (next weights, its share of the next halo)
                 if (!HOLO_CONV_PRIVATE_B || tap == kLast) __syncthreads();   // shared data: everybody's DMAs have landed
+            }
+#endif
+#if HOLO_CONV_STAMPS
+            {
+                HOLO_STAMP(t_end);
+                if (blockIdx.x == 1000 && tid == 0) {
+                    holo_dbg[0] += t_end - t_start;          // whole stage
+                    holo_dbg[1] += t_dma1 - t_dma0;          // staging-load issue
+                    holo_dbg[2] += t_end - t_mfma_end;       // wait + barrier
+                    holo_dbg[3] += 1;
+                }
             }
 #endif
             bpar ^= 1;
@@ -875,5 +908,13 @@ int holo_convt2x2_f32s(const void* x_nhwc, const void* w_packed, const float* bi
     return holo::convt2x2_entry<split16>(static_cast<const split16*>(x_nhwc), static_cast<const split16*>(w_packed), bias,
                                          static_cast<split16*>(y_nhwc), batch, h, w, cin, cout, relu, stream);
 }
+
+#if HOLO_CONV_STAMPS
+int holo_debug_read(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(holo::holo_dbg), 64); }
+int holo_debug_reset() {
+    unsigned long long z[8] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(holo::holo_dbg), z, 64);
+}
+#endif
 
 }  // extern "C"

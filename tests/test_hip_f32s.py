@@ -121,3 +121,20 @@ def test_whole_path_f32s(dev, s, b):
     assert rel(a.cpu(), a_r) < 1e-4 and rel(p.cpu(), p_r) < 1e-4 and rel(d.cpu(), d_r) < 1e-4
     assert rel(a.cpu(), a64) < 1.5 * rel(a32.cpu(), a64) + 1e-6 and rel(p.cpu(), p64) < 1.5 * rel(p32.cpu(), p64) + 1e-6
     assert rel(feats.cpu(), orc.encode(content, sds[0])) < 1e-4
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 300.0])
+def test_conv3x3_f32s_dynamic_range(ops, dev, scale):
+    """Activations three orders of magnitude smaller / larger than unit scale: the split keeps 2^-22 relative precision
+    while both halves are normal fp16 numbers (|a| >= ~1e-4 ... 65504), so the layer error relative to its own output
+    scale does not move; only below ~1e-4 does the absolute floor of lo' (1.5e-11) show."""
+    g = torch.Generator().manual_seed(11)
+    b, h, w, cin, cout = 2, 12, 20, 128, 128
+    x = torch.randn(b, cin, h, w, generator=g) * scale
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    bias = torch.zeros(cout)
+    ref = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), wt.double())
+    xs = ops.cast(ops.to_nhwc(x.to(dev)), ops.F32S)
+    y = ops.conv3x3(xs, ops.pack_conv3x3(wt.to(dev), ops.F32S), bias.to(dev), cout, False, False)
+    err = rel(ops.as_nchw_view(ops.cast(y, torch.float32)).cpu(), ref)
+    assert err < (1e-6 if scale >= 1.0 else 4e-6)

@@ -120,6 +120,9 @@ def main():
                          "bf16 = bf16 MFMA with fp32 accumulation (configs[2]); the propagator is fp32 either way")
     args = ap.parse_args()
 
+    from style_transfer_based_holographic_imaging_amd import build as _build
+    if not os.environ.get("HOLO_HIP_LIB") and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        _build.build(verbose=False)      # no-op when the in-tree library is up to date; never while other ranks may have it mapped
     from style_transfer_based_holographic_imaging_amd import ops, shard, synth
     # RCCL ("nccl") on the GPU node; HOLO_DIST_BACKEND=gloo + HOLO_SHARE_GPU=1 rehearse the multi-rank control flow
     # with several ranks on ONE card (the one-GPU development box)

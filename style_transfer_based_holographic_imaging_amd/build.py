@@ -27,12 +27,33 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _deps():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "holo_hip.h")]
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+HASH_FILE = OUT + ".srchash"
+
+
 def needs_build():
+    """True when the library is missing or was built from other sources.  Decided by a content hash written next to the
+    library (file times do not survive the copy to the GPU box); without the hash file, by modification times."""
     if not os.path.exists(OUT):
         return True
+    if os.path.exists(HASH_FILE):
+        with open(HASH_FILE) as f:
+            return f.read().strip() != _source_hash()
     t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "holo_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force: bool = False, verbose: bool = True):
@@ -43,6 +64,8 @@ def build(force: bool = False, verbose: bool = True):
     if verbose:
         print("[holo build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(HASH_FILE, "w") as f:
+        f.write(_source_hash() + "\n")
     return OUT
 
 

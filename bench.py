@@ -80,24 +80,32 @@ def cpu_baseline(size, sds, style, sample, seed):
                       f"torch {torch.__version__} CPU"}
 
 
-def pmc_traffic(batch, size):
-    """HBM bytes per conv launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
-    command (profiles/r01_pmc_conv_mfma.json; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  Counters cannot
-    be read from inside the process, so the number is only reported for the workload it was collected on."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_conv_mfma.json")
-    if (batch, size) != (64, 256) or not os.path.isfile(path):
-        return None
-    with open(path) as f:
-        return round(json.load(f)["conv_mfma_hbm_bytes_per_launch_avg"])
+PMC_PROFILE = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
 
 
-def pmc_traffic_asm(batch, size):
-    """HBM bytes per propagator call from profiles/r01_pmc_asm_propagate.json (same provenance as pmc_traffic)."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_asm_propagate.json")
-    if (batch, size) != (64, 256) or not os.path.isfile(path):
-        return None
-    with open(path) as f:
-        return round(json.load(f)["hbm_bytes_per_call"])
+def pmc_traffic(batch, size, dtype, distances):
+    """HBM bytes (conv: per launch; propagator: per call) from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    over this same command (scripts/collect_pmc.py -> profiles/r02_pmc_traffic.json; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md §HBM).  Counters cannot be read from inside the process, so the numbers are only reported for the
+    workload AND the library build they were collected on (the profile stores the library's source hash): anything else
+    gives null rather than a stale figure."""
+    if (batch, size, dtype, distances) != (64, 256, "f32", 1) or not os.path.isfile(PMC_PROFILE):
+        return None, None, None
+    from style_transfer_based_holographic_imaging_amd import _lib
+    with open(PMC_PROFILE) as f:
+        prof = json.load(f)
+    if prof.get("bench_args") or prof.get("source_hash") != _lib.lib.holo_source_hash().decode():
+        return None, None, None
+    label = f"profiles/{os.path.basename(PMC_PROFILE)}, collected on library {prof['source_hash'][:12]} (separate rocprofv3 --pmc passes)"
+    conv = prof.get("conv_mfma_hbm_bytes_per_launch_avg")
+    asm = prof.get("asm_hbm_bytes_per_call")
+    return (round(conv) if conv else None), (round(asm) if asm else None), label
+
+
+class HoloParams:
+    """The five attributes Holo_Generator reads from ``args`` (utils/Forward_model.py:9-13) with the entry script's
+    defaults (test_field_retrieval_mnist.py:56-60)."""
+    wavelength, pixel_size, distance_normalize, distance_normalize_constant, phase_normalize = 532e-9, 1.5e-6, 1.0, 0.0, 1.0
 
 
 def main():
@@ -121,8 +129,8 @@ def main():
     args = ap.parse_args()
 
     from style_transfer_based_holographic_imaging_amd import build as _build
-    if not os.environ.get("HOLO_HIP_LIB") and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        _build.build(verbose=False)      # no-op when the in-tree library is up to date; never while other ranks may have it mapped
+    if not os.environ.get("HOLO_HIP_LIB"):
+        _build.build(verbose=False)      # no-op when the in-tree library is up to date; locked + atomic rename, so every rank may call it
     from style_transfer_based_holographic_imaging_amd import ops, shard, synth
     # RCCL ("nccl") on the GPU node; HOLO_DIST_BACKEND=gloo + HOLO_SHARE_GPU=1 rehearse the multi-rank control flow
     # with several ranks on ONE card (the one-GPU development box)
@@ -145,8 +153,6 @@ def main():
         network.set_compute_dtype(torch.bfloat16)
     elif args.dtype == "f32s":   # opt-in: fp32 values as split fp16 halves on the fp16 matrix cores (never the default)
         network.set_compute_dtype("f32s")
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    from holo_oracle import HoloParams
     model_forward = Holo_Generator(HoloParams())
     style_cpu = torch.load(os.path.join(REPO, "style_representation", args.style, "style_vector.pt"), map_location="cpu").float()
     style = style_cpu.to(dev)
@@ -238,6 +244,7 @@ def main():
         }
         if timer is not None:
             summ = timer.summary()
+            traffic_conv, traffic_asm, traffic_src = pmc_traffic(b, s, args.dtype, args.distances)
             conv = [summ[k] for k in (f"holo_conv3x3_{args.dtype}", f"holo_convt2x2_{args.dtype}") if k in summ]
             # f32s: algorithmic fp32 FLOP against the fp16 matrix peak / 3 (three MFMA products per operand pair)
             peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32s": round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)}[args.dtype]
@@ -247,7 +254,7 @@ def main():
                 calls = sum(r["calls"] for r in conv)
                 ach = fl / (ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                                   "frac": round(ach / peak, 4), "traffic": pmc_traffic(b, s) if args.dtype == "f32" else None,
+                                   "frac": round(ach / peak, 4), "traffic": traffic_conv, "traffic_source": traffic_src,
                                    "algorithmic_bytes_per_launch": round(sum(r["bytes"] for r in conv) / calls),
                                    "kernel": f"conv_mfma_kernel<{args.dtype}> (3x3 + transposed, all layers)",
                                    "launches_per_step": calls // args.steps, "avg_launch_ms": round(ms / calls, 4),
@@ -256,7 +263,7 @@ def main():
                 r = summ["holo_asm_propagate"]
                 gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9
                 out["roofline_propagator"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                              "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": pmc_traffic_asm(b, s),
+                                              "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic_asm, "traffic_source": traffic_src,
                                               "algorithmic_bytes_per_call": round(r["bytes"] / r["calls"]),
                                               "kernel": "asm_rows_fwd + asm_cols + asm_rows_inv (80*S^2 B per field)",
                                               "avg_call_ms": round(r["ms"] / r["calls"], 4)}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 1
+#define HOLO_ABI_VERSION 2
 
 /* error codes */
 #define HOLO_OK 0
@@ -39,6 +39,14 @@ int holo_abi_version(void);
 const char* holo_last_error(void);
 /* name of the device code object's target ("gfx950"); fails the load on any other build */
 const char* holo_target_arch(void);
+/* hash of the sources, compiler flags and ROCm version this library was built from (the build recipe passes it as
+ * -DHOLO_SOURCE_HASH); the Python binding compares it with the hash of the sources next to it on every load, on
+ * every rank, and refuses a stale library */
+const char* holo_source_hash(void);
+/* Test / A-B hook, not part of the reference's surface: force a tile variant of holo_conv3x3_* (0 = automatic, the
+ * shipped behaviour; 1 = standard tile, 2 = small tile, 3 = tall bf16 wave tile).  All variants give bit-identical
+ * results (tests/test_hip_bf16.py).  Process-wide. */
+int holo_debug_set_conv_tile(int tile);
 
 /* ------------------------------------------------------------------------------------------
  * Weight packing (done once per module; reference keeps OIHW / IOHW tensors, net.py:33-130)

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""HBM traffic of the hot kernels from rocprofv3 PMC counters, as MI355X_MICROARCH.md §HBM prescribes:
+FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one), --kernel-trace only (no other trace
+domain), FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), units KiB -> bytes.  Each pass runs
+
+    rocprofv3 --kernel-trace --pmc <COUNTER> -d <dir> -o pmc --output-format csv -- python3 bench.py \
+        --steps 2 --warmup 1 --cpu-sample 0 --no-events [bench args]
+
+and only the LAST step's dispatches are summed (the first ones include weight packing and cold caches).
+Writes profiles/<name>.json with the hash of the library the numbers belong to; bench.py reports
+`roofline.traffic` from that file only while the hash matches the loaded library.
+
+    python scripts/collect_pmc.py --out profiles/r02_pmc_traffic.json [-- bench args]
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+CONV = "conv_mfma_kernel"
+ASM = ("asm_rows_fwd_kernel", "asm_cols_kernel", "asm_cols_persistent_kernel", "asm_rows_inv_kernel")
+
+
+def one_pass(counter, outdir, bench_args):
+    os.makedirs(outdir, exist_ok=True)
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", outdir, "-o", "pmc", "--output-format", "csv", "--",
+           sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-events"] + bench_args
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise SystemExit(f"rocprofv3 pass {counter} failed ({r.returncode}):\n{r.stderr[-2000:]}")
+    files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no counter_collection.csv under {outdir}")
+    rows = []
+    with open(sorted(files)[-1]) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == counter:
+                rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def last_step(rows):
+    """dispatches of the last bench step: from the last conv_first launch on (each step starts with it)"""
+    starts = [i for i, r in enumerate(rows) if "conv_first_kernel" in r[1]]
+    # bench: 1 warm-up + 2 timed steps + (unwrap probe step, f32s steps) afterwards; take the 3rd start (2nd timed step)
+    i0 = starts[2] if len(starts) > 2 else starts[-1]
+    i1 = starts[3] if len(starts) > 3 else len(rows)
+    return rows[i0:i1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "profiles", "r02_pmc_traffic.json"))
+    ap.add_argument("--scratch", default=os.path.join(REPO, "gpurun_out", "pmc_r02"))
+    ap.add_argument("bench_args", nargs="*")
+    args = ap.parse_args()
+    from style_transfer_based_holographic_imaging_amd import build
+    build.build(verbose=False)
+    res = {}
+    for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+        rows = last_step(one_pass(counter, os.path.join(args.scratch, counter.lower()), args.bench_args))
+        for _, name, val in rows:
+            short = name.split("(")[0]
+            key = "conv" if CONV in short else next((k for k in ASM if k in short), None)
+            if key is None:
+                continue
+            r = res.setdefault(key, {"launches": {}, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+            r[counter] += val * scale
+            r["launches"][counter] = r["launches"].get(counter, 0) + 1
+    out = {"source": __doc__.split("\n\n")[0].replace("\n", " "), "bench_args": args.bench_args,
+           "source_hash": build.source_hash(), "kernels": {}}
+    for key, r in res.items():
+        n = max(r["launches"].values())
+        out["kernels"][key] = {"launches_per_step": n, "hbm_read_bytes_per_step": r["FETCH_SIZE"],
+                               "hbm_write_bytes_per_step": r["WRITE_SIZE"]}
+    if "conv" in out["kernels"]:
+        c = out["kernels"]["conv"]
+        out["conv_mfma_hbm_bytes_per_launch_avg"] = (c["hbm_read_bytes_per_step"] + c["hbm_write_bytes_per_step"]) / c["launches_per_step"]
+    asm = [v for k, v in out["kernels"].items() if k in ASM]
+    if asm:
+        out["asm_hbm_bytes_per_call"] = sum(v["hbm_read_bytes_per_step"] + v["hbm_write_bytes_per_step"] for v in asm)
+    with open(args.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,8 @@ SIGNATURES = {
     "holo_abi_version": (_i, []),
     "holo_last_error": (C.c_char_p, []),
     "holo_target_arch": (C.c_char_p, []),
+    "holo_source_hash": (C.c_char_p, []),
+    "holo_debug_set_conv_tile": (_i, [_i]),
     "holo_pack_conv3x3_weight_f32": (_i, [_p, _p, _i, _i, _p]),
     "holo_conv3x3_packed_elems": (_z, [_i, _i]),
     "holo_pack_convt2x2_weight_f32": (_i, [_p, _p, _i, _i, _p]),
@@ -71,7 +73,7 @@ SIGNATURES = {
 
 ASM_IN_AMP_PHASE, ASM_IN_COMPLEX = 0, 1
 ASM_OUT_AMP_PHASE, ASM_OUT_INTENSITY, ASM_OUT_COMPLEX = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HoloLibraryError(RuntimeError):
@@ -93,6 +95,15 @@ def _load():
         fn.argtypes = args
     if lib.holo_abi_version() != ABI_VERSION:
         raise HoloLibraryError(f"ABI version {lib.holo_abi_version()} != expected {ABI_VERSION}")
+    # a library built from other sources (same symbols, e.g. another weight-packing layout) must not load silently —
+    # checked on every rank of a multi-process job.  HOLO_HIP_LIB (an explicitly chosen A/B build) opts out.
+    if not os.environ.get("HOLO_HIP_LIB"):
+        from . import build as _build
+        built, here = lib.holo_source_hash().decode(), _build.source_hash()
+        if built != here:
+            raise HoloLibraryError(
+                f"{LIB_PATH} was built from other sources (library {built[:12]}, tree {here[:12]}): rebuild it "
+                "(python -c 'import __graft_entry__ as g; g.build()')")
     return lib
 
 

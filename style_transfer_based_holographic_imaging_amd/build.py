@@ -2,10 +2,19 @@
 
 No torch extension machinery: the boundary is a plain C-ABI (``include/holo_hip.h``) loaded with
 ctypes, so the library builds without a GPU and travels to the GPU box inside the repo snapshot.
+
+Staleness is decided by ``source_hash()`` — sources, headers, compiler flags and the ROCm version —
+which is compiled into the library (``holo_source_hash()``) and compared by ``_lib`` on every load.
+The compiler writes to a temporary file that is renamed over the library under a file lock, so
+concurrent builders (pytest next to bench, xdist workers) neither clobber each other nor expose a
+half-written object to ``dlopen``.
 """
 from __future__ import annotations
 
+import fcntl
 import glob
+import hashlib
+import mmap
 import os
 import subprocess
 import sys
@@ -13,7 +22,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libholo_hip.so")
+LOCK = OUT + ".lock"
 ARCH = "gfx950"
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
 
 
 def _hipcc():
@@ -31,42 +42,68 @@ def _deps():
     return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "holo_hip.h")]
 
 
-def _source_hash():
-    import hashlib
+def _rocm_version():
+    try:
+        with open("/opt/rocm/.info/version") as f:
+            return f.read().strip()
+    except OSError:
+        return "unknown"
+
+
+def source_hash(extra_flags=()):
+    """sha256 over the sources and headers, the compiler flags and the ROCm version."""
     h = hashlib.sha256()
     for d in _deps():
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
             h.update(f.read())
+    h.update(" ".join(FLAGS + list(extra_flags)).encode())
+    h.update(_rocm_version().encode())
     return h.hexdigest()
 
 
-HASH_FILE = OUT + ".srchash"
+_TAG = b"@(#)holo_source_hash="
+
+
+def built_hash(path=OUT):
+    """The hash compiled into a built library (what its holo_source_hash() returns), or None (missing / unreadable /
+    older ABI).  Read from the file's bytes: loading it here would pin a stale image in this process (dlopen returns
+    the already-loaded object for the same path after a rebuild)."""
+    try:
+        with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as m:
+            i = m.find(_TAG)
+            if i < 0:
+                return None
+            raw = m[i + len(_TAG): i + len(_TAG) + 64]
+            return raw.split(b"\0")[0].decode("ascii", "replace")
+    except (OSError, ValueError):
+        return None
 
 
 def needs_build():
-    """True when the library is missing or was built from other sources.  Decided by a content hash written next to the
-    library (file times do not survive the copy to the GPU box); without the hash file, by modification times."""
-    if not os.path.exists(OUT):
-        return True
-    if os.path.exists(HASH_FILE):
-        with open(HASH_FILE) as f:
-            return f.read().strip() != _source_hash()
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    """True when the library is missing or was built from other sources / flags / ROCm."""
+    return built_hash() != source_hash()
 
 
-def build(force: bool = False, verbose: bool = True):
-    if not force and not needs_build():
-        return OUT
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", OUT] + sources()
-    if verbose:
-        print("[holo build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    with open(HASH_FILE, "w") as f:
-        f.write(_source_hash() + "\n")
-    return OUT
+def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = OUT):
+    """Build (if stale) and return the library path.  `extra_flags` / `out` make side builds
+    (-DHOLO_DEBUG ablation knobs, -DHOLO_CONV_STAMPS=1) that never replace the shipped library."""
+    want = source_hash(extra_flags)
+    with open(LOCK if out == OUT else out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and built_hash(out) == want:     # re-checked under the lock: another process may just have built it
+            return out
+        tmp = f"{out}.tmp.{os.getpid()}"
+        cmd = [_hipcc()] + FLAGS + list(extra_flags) + [f'-DHOLO_SOURCE_HASH="{want}"', "-o", tmp] + sources()
+        if verbose:
+            print("[holo build]", " ".join(cmd), flush=True)
+        try:
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+    return out
 
 
 if __name__ == "__main__":

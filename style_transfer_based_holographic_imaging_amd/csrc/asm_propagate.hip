@@ -490,7 +490,7 @@ struct AsmArgs {
     double* f2;
     float2 *tbuf, *ubuf;
     hipStream_t stream;
-    int ablate;   // debug only (HOLO_ASM_ABLATE): 1 = skip H evaluation, 2 = skip the FFT passes
+    int ablate;   // -DHOLO_DEBUG builds only (HOLO_ASM_ABLATE): 1 = skip H evaluation, 2 = skip the FFT passes; 0 in the shipped build
 };
 
 template <int P, bool PAD>
@@ -502,8 +502,8 @@ static int launch_asm(const AsmArgs& a) {
     const size_t row_lds_f = (size_t)(tw_entries_fwd<P>() + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
     const size_t row_lds_i = (size_t)(tw_entries_inv<P>() + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
     const size_t col_lds = C::LDS;
-    static bool attr_done = false;  // idempotent; a race only repeats the call
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;  // per device; idempotent, a race only repeats the call
+    if (first_call_on_device(attr_done)) {
         if (col_lds > 48 * 1024)
         {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_kernel<P, PAD>),
@@ -517,7 +517,6 @@ static int launch_asm(const AsmArgs& a) {
         if (row_lds_i > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
-        attr_done = true;
     }
     const long rows_in = (long)a.n_fields * S;
     hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kRowThreads),
@@ -746,10 +745,13 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
     a.tbuf = reinterpret_cast<float2*>(static_cast<unsigned char*>(workspace) + kTableBytes);
     a.ubuf = a.tbuf + (size_t)n_fields * s * p;
     a.stream = as_stream(stream);
+    a.ablate = 0;
+#ifdef HOLO_DEBUG   // timing experiments only (wrong results): never read in the shipped build
     {
         const char* env = getenv("HOLO_ASM_ABLATE");
         a.ablate = env ? atoi(env) : 0;
     }
+#endif
     const bool pad = zero_padding != 0;
     if (!fast) return launch_asm_generic(a, p, s, pad ? s / 2 : 0);
     switch (p) {

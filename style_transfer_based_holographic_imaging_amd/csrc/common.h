@@ -28,6 +28,21 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-device one-time set-up (hipFuncSetAttribute for > 48 KB of dynamic LDS is a property of the function ON A DEVICE):
+// `mask` is a function-local static bit set of the devices already prepared.  A race only repeats the idempotent call.
+inline bool first_call_on_device(unsigned long long& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: set the attributes every time
+    const unsigned long long bit = 1ull << dev;
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
+// tile selection of the 3x3 / transposed convolutions: 0 = automatic (shipped), 1..3 force a variant (holo_debug_set_conv_tile,
+// used by the tests that hold the variants bit-identical)
+int conv_tile_override();
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ReflectionPad2d(1) index: -1 -> 1, n -> n-2 (n >= 2); anything further out is clamped so that

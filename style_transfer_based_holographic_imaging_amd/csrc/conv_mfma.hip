@@ -672,13 +672,10 @@ static int launch_conv(const T* x, const T* wp, const float* bias, T* y, int bat
     const int tiles_x = ceil_div(w, kPW), tiles_y = ceil_div(h, C::PR);
     const long blocks = (long)batch * tiles_x * tiles_y * (n / C::TN);
     HOLO_REQUIRE(blocks > 0 && blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "conv: grid of %ld blocks", blocks);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (C::LDS_BYTES > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, CONVT, KC, T, WTM, WTN>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;   // per device
+    if (C::LDS_BYTES > 48 * 1024 && first_call_on_device(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, CONVT, KC, T, WTM, WTN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, CONVT, KC, T, WTM, WTN>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
                        stream, x, wp, bias, y, h, w, cin, cout, n, tiles_x, tiles_y, relu, pool);
     return check_launch(CONVT ? "holo_convt2x2" : "holo_conv3x3");
@@ -787,9 +784,8 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
                  "holo_conv3x3_%s: one image must stay below 2^30 elements (32-bit byte offsets)", dtype_name<T>());
     hipStream_t s = as_stream(stream);
     constexpr int KCD = (sizeof(T) == 2 || __is_same(T, split16)) ? 32 : 16;   // default K chunk of the dtype
-    // HOLO_CONV_TILE (tests, A/B runs; read per call): 1 = standard tile, 2 = small tile, 3 = tall bf16 wave tile
-    const char* tile_env = getenv("HOLO_CONV_TILE");
-    const int force = tile_env ? atoi(tile_env) : 0;
+    // holo_debug_set_conv_tile (tests, A/B runs): 1 = standard tile, 2 = small tile, 3 = tall bf16 wave tile; 0 = automatic
+    const int force = conv_tile_override();
     // Small problems (e.g. the bundled 5 x 128x128 batches): with the 128-px x 128-co (or 256 x 64) block tile a
     // layer has only 40-320 blocks for 256 CUs.  Below ~2 blocks per CU switch to the 64 px x 64 co tile: 4x
     // the blocks, each a quarter of the work.  Weight packing does not depend on the tile.
@@ -799,7 +795,7 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
             return launch_conv<2, 2, false, KCD, T, 1>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
     }
     if constexpr (sizeof(T) == 2) {
-        // Experiment, off unless HOLO_CONV_TILE=3: wave tile 128 px x 64 co (4x2 MFMA tiles; 256 px x 128 co blocks,
+        // Experiment, off unless holo_debug_set_conv_tile(3): wave tile 128 px x 64 co (4x2 MFMA tiles; 256 px x 128 co blocks,
         // or 512 px x 64 co for the 64-wide layers).  It halves the staged and re-read LDS bytes per MFMA, yet measured
         // SLOWER on MI355X (batch 64, 256x256: 746 TFLOP/s with 64-channel stages / one block per CU, 833 with
         // 32-channel stages / two blocks per CU, against 898 for the 64 x 64 wave tile): results are bit-identical.
@@ -815,7 +811,7 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
     if constexpr (__is_same(T, split16)) {
         // split operands carry three accumulator sets (main, cross terms, fold): with the 64 px x 64 co wave tile that is 384
         // VGPRs and one wave per SIMD; the 64 px x 32 co wave tile (222 VGPRs, two waves per SIMD, block 128 px x 64 co) is
-        // 8 % faster (12.3 vs 13.5 ms of conv per step at batch 64 x 256^2).  HOLO_CONV_TILE=1 selects the wide tile.
+        // 8 % faster (12.3 vs 13.5 ms of conv per step at batch 64 x 256^2).  holo_debug_set_conv_tile(1) selects the wide tile.
         if (force != 1) return launch_conv<2, 2, false, KCD, T, 2, 1>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
     }
     if (cout % 128 == 0) {

@@ -131,8 +131,15 @@ __global__ __launch_bounds__(kUnwrapThreads) void unwrap_boruvka_kernel(const fl
     constexpr u64 kNoKey = ~0ull;
 
     // a grid of n pixels needs at most ceil(log2 n) <= 24 rounds; both loops are capped so the block always exits
+#ifdef HOLO_DEBUG   // profiling build only (scripts/unwrap_stats.py): rounds, sweeps and clock ticks per phase
     int n_rounds = 0, n_jumps = 0;
     long long t_edge = 0, t_hook = 0, t_jump = 0, t0 = wall_clock64(), t1;
+#define HOLO_UNWRAP_STAMP(acc_) do { t1 = wall_clock64(); acc_ += t1 - t0; t0 = t1; } while (0)
+#define HOLO_UNWRAP_COUNT(var_) ++var_
+#else
+#define HOLO_UNWRAP_STAMP(acc_) do { } while (0)
+#define HOLO_UNWRAP_COUNT(var_) do { } while (0)
+#endif
     for (int round = 0; round < kMaxRounds; ++round) {
         const u64 tag = (u64)(kMaxRounds - round) << kTagShift;  // 1..30: never the 31 of an untouched slot
         int any = 0;
@@ -234,8 +241,8 @@ __global__ __launch_bounds__(kUnwrapThreads) void unwrap_boruvka_kernel(const fl
             }
         }
         if (!__syncthreads_or(any)) break;  // one group left
-        ++n_rounds;
-        t1 = wall_clock64(); t_edge += t1 - t0; t0 = t1;
+        HOLO_UNWRAP_COUNT(n_rounds);
+        HOLO_UNWRAP_STAMP(t_edge);
         // ---- hook sweep: roots follow their edge (writes touch root entries only)
         for (int base = tid; base < n; base += kUnwrapThreads * kBatchHook) {
             u64 b[kBatchHook], nu[kBatchHook], nv[kBatchHook];
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(kUnwrapThreads) void unwrap_boruvka_kernel(const fl
             }
         }
         __syncthreads();
-        t1 = wall_clock64(); t_hook += t1 - t0; t0 = t1;
+        HOLO_UNWRAP_STAMP(t_hook);
         // ---- pointer jumping with offsets until every pixel points at its root
         for (int it = 0; it < kMaxJumps; ++it) {
             int changed = 0;
@@ -313,17 +320,21 @@ __global__ __launch_bounds__(kUnwrapThreads) void unwrap_boruvka_kernel(const fl
                     changed = 1;
                 }
             }
-            ++n_jumps;
+            HOLO_UNWRAP_COUNT(n_jumps);
             if (!__syncthreads_or(changed)) break;
         }
-        t1 = wall_clock64(); t_jump += t1 - t0; t0 = t1;
+        HOLO_UNWRAP_STAMP(t_jump);
     }
-    // rounds and pointer-jumping sweeps it took, for profiling (the edge slots are dead from here on)
-    if (tid == 0 && n >= 2) {
+#ifdef HOLO_DEBUG
+    // rounds and pointer-jumping sweeps it took (the edge slots are dead from here on)
+    if (tid == 0 && n >= 5) {
         best[0] = (u64)n_rounds;
         best[1] = (u64)n_jumps;
         best[2] = (u64)t_edge; best[3] = (u64)t_hook; best[4] = (u64)t_jump;
     }
+#endif
+#undef HOLO_UNWRAP_STAMP
+#undef HOLO_UNWRAP_COUNT
 
     // ---- re-base: the most frequent offset becomes 0 (lowest offset wins a tie)
     for (int i = tid; i < kHistBins; i += kUnwrapThreads) hist[i] = 0;

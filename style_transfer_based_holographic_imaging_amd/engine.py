@@ -10,7 +10,9 @@ into steps, each one C-ABI call:
     ConvTranspose2d(k2,s2) [. ReLU]                                       -> convt2x2
     ReflectionPad2d . Conv2d(64,2,3x3)                                    -> conv_last (NCHW planes out)
 
-Packed weights are cached per plan and rebuilt when a parameter changes (version counter / device).
+Packed weights are cached per plan and rebuilt when a parameter changes (version counter / data pointer of every
+parameter of the step; ``load_state_dict`` and ``_apply`` also drop the cache).  Writes through ``param.data`` bump no
+version counter: call ``invalidate_packed_weights()`` after one.
 """
 from __future__ import annotations
 
@@ -99,7 +101,8 @@ class Plan:
 
     def _weights(self, idx, step):
         conv = step.conv
-        key = (conv.weight._version, conv.weight.data_ptr(), conv.bias._version, conv.bias.data_ptr())
+        key = tuple(v for m in (conv, step.conv0) if m is not None
+                    for v in (m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()))
         hit = self._packed.get(idx)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -117,6 +120,13 @@ class Plan:
             vals = (w.float().contiguous(), b)
         self._packed[idx] = (key, vals)
         return vals
+
+    def invalidate(self):
+        """Drop the packed weights.  The cache key (version counter + data pointer of every parameter of a step) sees
+        in-place ops, ``load_state_dict`` and ``.to()``; a write THROUGH ``param.data`` (``p.data.copy_()``,
+        ``p.data[...] = ``) bumps no version counter, so call this (or ``HoloSequential.invalidate_packed_weights``)
+        after one."""
+        self._packed.clear()
 
     @property
     def ends_in_planes(self):
@@ -158,6 +168,23 @@ class HoloSequential(nn.Sequential):
         dtype = ops.compute_dtype(dtype)      # also "f32s": fp32 values as split fp16 halves on the fp16 matrix cores
         object.__setattr__(self, "_holo_dtype", dtype)
         return self
+
+    def invalidate_packed_weights(self):
+        """Forget the packed (MFMA-layout) copies of the weights; they are rebuilt on the next forward."""
+        plan = getattr(self, "_holo_plan", None)
+        if plan is not None:
+            plan.invalidate()
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed_weights()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):       # .to() / .cuda() / .float() ...
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packed_weights()
+        return out
 
     def _plan(self):
         dtype = getattr(self, "_holo_dtype", torch.float32)

@@ -17,16 +17,35 @@ from . import _lib
 from ._lib import check, lib
 
 
+# device of the launch being prepared: set by _req from the tensors of the call, read by _stream / _launch.  A launch
+# goes to the current stream OF THE TENSORS' DEVICE and is issued with that device current (the C-ABI launches on
+# whatever device is current, and hipFuncSetAttribute is per device), whatever torch.cuda.current_device() says.
+_DEV = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(_DEV).cuda_stream
 
 
 def _req(*tensors):
+    global _DEV
+    dev = None
     for t in tensors:
         if not isinstance(t, torch.Tensor) or not t.is_cuda:
             raise RuntimeError(
                 "holo HIP ops need tensors on a ROCm device (the MI355X path has no CPU fallback); "
                 f"got {type(t).__name__} on {getattr(t, 'device', None)}")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"holo HIP ops need all tensors of a call on one device; got {dev} and {t.device}")
+    _DEV = dev
+
+
+def set_conv_tile(tile: int):
+    """Test / A-B hook (include/holo_hip.h: holo_debug_set_conv_tile): force a tile variant of the 3x3 convolution;
+    0 restores the automatic choice."""
+    check(lib.holo_debug_set_conv_tile(int(tile)), "holo_debug_set_conv_tile")
 
 
 def _f32c(t):
@@ -133,6 +152,9 @@ _TIMER = None
 def _launch(name, fn, flops=0.0, nbytes=0.0, fresh=False):
     """fresh=True: start this launch's clock right before it (used where torch's own small element-wise launches
     precede ours and must not be charged to the kernel's roofline figure)."""
+    if _DEV is not None and _DEV.index != torch.cuda.current_device():
+        with torch.cuda.device(_DEV):      # e.g. --device cuda:1 without torch.cuda.set_device
+            return _launch(name, fn, flops, nbytes, fresh)
     if _TIMER is None:
         check(fn(), name)
         return

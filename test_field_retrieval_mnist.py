@@ -98,6 +98,9 @@ def main(argv=None):
     from utils import metrics
 
     device = torch.device(args.device)
+    # make `--device cuda:N` the current device too: torch's own allocations / streams follow the current device
+    # (the HIP ops launch on their tensors' device either way)
+    torch.cuda.set_device(device if device.index is not None else torch.cuda.current_device())
     args.save_dir = args.save_dir + '/%s' % args.exp_name
     output_dir = Path(args.save_dir)
     output_dir.mkdir(exist_ok=True, parents=True)

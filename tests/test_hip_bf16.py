@@ -55,7 +55,7 @@ def test_conv3x3_bf16(ops, dev, b, h, w, cin, cout, relu, pool):
     (2, 32, 32, 64, 128, True, False), (1, 21, 37, 128, 128, True, True), (1, 16, 16, 256, 256, False, False),
     (2, 64, 48, 64, 64, True, True), (1, 35, 19, 128, 64, True, False), (1, 2, 2, 32, 64, True, False),
 ])
-def test_conv3x3_bf16_tall_wave_tile(ops, dev, monkeypatch, b, h, w, cin, cout, relu, pool):
+def test_conv3x3_bf16_tall_wave_tile(ops, dev, b, h, w, cin, cout, relu, pool):
     """The 128 px x 64 co wave tile (256 px x 128 co and 512 px x 64 co blocks) used for large bf16 layers, forced
     here on small shapes with partial tiles; bit-identical to the standard tile (same K order per accumulator)."""
     g = torch.Generator().manual_seed(h * 100 + cin + 7)
@@ -69,10 +69,13 @@ def test_conv3x3_bf16_tall_wave_tile(ops, dev, monkeypatch, b, h, w, cin, cout, 
         ref = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
     xp = ops.cast(ops.to_nhwc(x.to(dev)), BF)
     wp = ops.pack_conv3x3(wt.to(dev), BF)
-    monkeypatch.setenv("HOLO_CONV_TILE", "3")
-    y = ops.conv3x3(xp, wp, bias.to(dev), cout, relu, pool)
-    monkeypatch.setenv("HOLO_CONV_TILE", "1")
-    y_std = ops.conv3x3(xp, wp, bias.to(dev), cout, relu, pool)
+    try:
+        ops.set_conv_tile(3)
+        y = ops.conv3x3(xp, wp, bias.to(dev), cout, relu, pool)
+        ops.set_conv_tile(1)
+        y_std = ops.conv3x3(xp, wp, bias.to(dev), cout, relu, pool)
+    finally:
+        ops.set_conv_tile(0)
     got = ops.as_nchw_view(y).float().cpu()
     assert got.shape == ref.shape and rel_err(got, ref) < 6e-3
     assert torch.equal(y, y_std)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/holo_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), "ctypes SIGNATURES and the header disagree"
-    assert _lib.lib.holo_abi_version() == 1
+    assert _lib.lib.holo_abi_version() == 2
     assert _lib.lib.holo_target_arch() == b"gfx950"
 
 
@@ -179,3 +179,101 @@ def test_unwrap_has_no_host_fallback():
     except ImportError:
         with pytest.raises(ImportError, match="scikit-image"):
             unwrap(torch.zeros(1, 1, 8, 8))
+
+
+# ---- round-2 advisor items ----------------------------------------------------------------------------------------
+def test_library_carries_the_hash_of_its_sources_and_a_stale_one_is_refused(monkeypatch):
+    """The hash of sources + flags + ROCm version is compiled into the library; build.py reads it from the file and
+    _lib compares it on every load (every rank): a library built from other sources does not load silently."""
+    from style_transfer_based_holographic_imaging_amd import _lib, build
+    here = build.source_hash()
+    assert build.built_hash() == here == _lib.lib.holo_source_hash().decode()
+    assert build.source_hash(("-DHOLO_DEBUG",)) != here            # flags are part of the hash
+    assert not build.needs_build()
+    monkeypatch.setattr(build, "source_hash", lambda *a: "0" * 64)
+    monkeypatch.delenv("HOLO_HIP_LIB", raising=False)
+    with pytest.raises(_lib.HoloLibraryError, match="built from other sources"):
+        _lib._load()
+
+
+def test_debug_tile_hook_validates_its_argument():
+    from style_transfer_based_holographic_imaging_amd._lib import lib
+    assert lib.holo_debug_set_conv_tile(7) == 1 and b"outside [0,3]" in lib.holo_last_error()
+    assert lib.holo_debug_set_conv_tile(0) == 0
+
+
+def test_ops_reject_tensors_on_different_devices_and_follow_the_tensors_device():
+    """ops._req: every tensor of a call must sit on ONE ROCm device, and that device (not torch's current one) picks
+    the stream and is made current around the launch."""
+    from unittest import mock
+    from style_transfer_based_holographic_imaging_amd import ops
+
+    def fake(idx):
+        t = mock.MagicMock(spec=torch.Tensor)
+        t.is_cuda, t.device = True, torch.device("cuda", idx)
+        return t
+    ops._req(fake(1), fake(1))
+    assert ops._DEV == torch.device("cuda", 1)
+    with pytest.raises(RuntimeError, match="one device"):
+        ops._req(fake(0), fake(1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops._req(fake(0), torch.zeros(1))
+    seen = []
+
+    def current_stream(d=None):
+        seen.append(d)
+        return mock.MagicMock(cuda_stream=0)
+    with mock.patch.object(torch.cuda, "current_stream", current_stream):
+        ops._req(fake(1))
+        ops._stream()
+    assert seen == [torch.device("cuda", 1)]
+    # a launch for a tensor on cuda:1 while cuda:0 is current switches the device around the call
+    entered = []
+
+    class Ctx:
+        def __init__(self, d):
+            entered.append(d)
+
+        def __enter__(self):
+            cur[0] = 1
+
+        def __exit__(self, *a):
+            cur[0] = 0
+    cur = [0]
+    with mock.patch.object(torch.cuda, "current_device", lambda: cur[0]), mock.patch.object(torch.cuda, "device", Ctx):
+        ops._req(fake(1))
+        ran = []
+        ops._launch("x", lambda: ran.append(cur[0]) or 0)
+    assert entered == [torch.device("cuda", 1)] and ran == [1]
+
+
+def test_packed_weight_cache_sees_the_pre_conv_and_can_be_invalidated():
+    """engine.Plan: the 'first' step's cache key covers vgg[0] (the 1x1 pre-conv) as well as the 3x3 conv; writes
+    through .data need invalidate()."""
+    import net
+    from style_transfer_based_holographic_imaging_amd.engine import HoloSequential, Plan
+    import copy
+    children = [copy.deepcopy(m) for m in list(net.vgg.children())[:4]]
+    plan = Plan(children)
+    st = plan.steps[0]
+    assert st.kind == "first" and st.conv0 is children[0]
+    a = plan._weights(0, st)
+    assert plan._weights(0, st) is a                       # cached
+    with torch.no_grad():
+        children[0].weight.add_(1.0)                       # in-place op on the PRE-conv: version counter moves
+    b = plan._weights(0, st)
+    assert b is not a and torch.equal(b[0], children[0].weight)
+    children[0].weight.data.mul_(2.0)                      # write through .data: no version bump -> stale until invalidated
+    assert plan._weights(0, st) is b
+    plan.invalidate()
+    c = plan._weights(0, st)
+    assert c is not b and torch.equal(c[0], children[0].weight)
+    # load_state_dict / _apply on the module drop the cache too
+    seq = HoloSequential(*children)
+    seq._plan()._weights(0, seq._plan().steps[0])
+    assert seq._plan()._packed
+    seq.load_state_dict(seq.state_dict())
+    assert not seq._plan()._packed
+    seq._plan()._weights(0, seq._plan().steps[0])
+    seq.float()
+    assert not seq._plan()._packed

@@ -75,6 +75,16 @@ int holo_conv_first_f32(const float* x, const float* w0, const float* b0, const 
 int holo_conv3x3_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc,
                      int batch, int h, int w, int cin, int cout, int relu, int pool, void* stream);
 
+/* The same layers (ReflectionPad2d(1) -> Conv2d(3x3) -> [ReLU] [-> MaxPool2d(2,2,ceil)], net.py:78-107 / 34-71) as
+ * Winograd F(2x2,3x3) in exact fp32 arithmetic on the fp32 matrix cores: 2.25x fewer multiplications; results differ
+ * from holo_conv3x3_f32 by fp32 rounding only (both ~1e-5 of the network's outputs away from a float64 evaluation).
+ * Weights: (Cout,Cin,3,3) -> G g G^T (float64, rounded once) as [Cout/32][Cin/16][4x4 position][32][16] fp32,
+ * 16*Cout*Cin floats.  Cin % 16 == 0, Cout % 32 == 0; shapes and flags as holo_conv3x3_f32. */
+int holo_pack_conv3x3_wino_weight_f32(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
+size_t holo_conv3x3_wino_packed_elems(int cout, int cin);
+int holo_conv3x3_wino_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc,
+                          int batch, int h, int w, int cin, int cout, int relu, int pool, void* stream);
+
 /* ConvTranspose2d(Cin,Cout,k=2,s=2) -> [ReLU] (net.py:40,55,64).  x: NHWC (B,H,W,Cin);
  * y: NHWC (B,2H,2W,Cout).  Cin % 16 == 0, Cout % 64 == 0. */
 int holo_convt2x2_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc,

@@ -93,6 +93,13 @@ class Net(nn.Module):
         self.decoder.set_compute_dtype(dtype)
         return self
 
+    def set_conv_algo(self, algo):
+        """Additive: "auto" (default), "direct" or "winograd" for the fp32 3x3 layers (engine.HoloSequential.set_conv_algo)."""
+        for k in range(self.n_layer):
+            getattr(self, f"enc_{k + 1}").set_conv_algo(algo)
+        self.decoder.set_conv_algo(algo)
+        return self
+
     @staticmethod
     def _public(feat):
         """Feature maps leave the module as fp32 (the optional "f32s" compute mode keeps them as split halves inside)."""

@@ -10,18 +10,26 @@
 // 2-D transform is three HBM-bound kernels (80*S^2 algorithmic bytes per field):
 //
 //   K1 rows_fwd : amp,phase (8S^2 B) -> pack a*e^{ip}, replicate-pad the ROW to P, row FFT
-//                 -> T[S][P] (16S^2 B).  The S/2 padded rows above/below the field are copies of
+//                 -> T (16S^2 B).  The S/2 padded rows above/below the field are copies of
 //                 its first/last row, so only S distinct row FFTs exist.  Inputs go straight from
-//                 global memory into the first butterfly's registers, outputs straight from the last
-//                 butterfly's registers to global memory (LDS only between passes).
-//   K2 cols     : T columns (16S^2 B) -> transposed into LDS, column FFT (replicate padding applied
-//                 by the first gather), multiply by H IN REGISTERS between the forward's last and the
-//                 inverse's first pass (same radix, same register layout), column IFFT, keep the S
-//                 centre rows -> U[S][P] (16S^2 B).  H is generated per block: float64 phase argument
-//                 from a precomputed f^2 table, range reduction in float64, fp32 sin/cos; rows ky and
-//                 P-ky share one value through an LDS table.
+//                 global memory into the first butterfly's registers.
+//   K2 cols     : T columns (16S^2 B) -> column FFT (replicate padding applied by the load), multiply
+//                 by H IN REGISTERS between the forward's last and the inverse's first pass (same radix,
+//                 same register layout), column IFFT, keep the S centre rows -> U (16S^2 B).  H is
+//                 generated per column: float64 phase argument, range reduction in float64, fp32
+//                 sin/cos; rows ky and P-ky share one value through an LDS table.
 //   K3 rows_inv : U rows (16S^2 B) -> row IFFT, keep the S centre columns, scale 1/P^2,
-//                 abs/angle | intensity | complex epilogue (8S^2 B), again register to global.
+//                 abs/angle | intensity | complex epilogue (8S^2 B), register to global.
+//
+// Layout of the intermediates (round 2): T and U are stored TRANSPOSED, [field][kx][y] (a column's S
+// values contiguous), for 32 <= P <= 1024.  The column kernel is the one limited by VALU + LDS + memory at
+// once, the row kernels are purely memory-bound with idle LDS — so the two transposes live in the ROW
+// kernels (16 rows per block through a padded LDS tile, 128-byte runs to/from memory) and the column kernel
+// moves its data register <-> global with no staging, no block barrier and one wave (or part of one) per
+// column: every wave runs load -> FFT -> H -> IFFT -> store on its own and the CU overlaps the phases of its
+// 28 waves.  (Round 1 staged 16-column tiles through LDS inside the column kernel: 2 barriers, 2 extra LDS
+// round trips per element, blocks of 1024 threads moving in lockstep.)  P = 2048 and the smallest padded
+// grid keep the row-major layout and the round-1 kernels.
 //
 // Transforms run in fp32 (complex64) with float64-rounded twiddles; the reference runs the product
 // and the inverse transform in complex128 and casts to float at the end
@@ -474,6 +482,265 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
     }
 }
 
+
+// ================================================================================================================
+// Transposed-intermediate kernels (32 <= P <= 1024, S a multiple of 16): T and U are [field][kx][y].
+// ================================================================================================================
+constexpr int kTileRows = 16;              // rows per row-kernel block: 16 x 8 B = one 128-B run per kx
+constexpr int kTilePitch = kTileRows + 1;  // LDS tile [kx][17]: conflict-free for 16 consecutive kx at a fixed row
+
+template <int P>
+struct RowTCfg {
+    static constexpr int G = FftGeom<P>::G, E = FftGeom<P>::E;
+    static constexpr int THREADS = kTileRows * G;                 // one row per G lanes
+    static constexpr int PITCH = fft_padded_len(P) + 1;
+    static constexpr int BUF = kTileRows * PITCH;                 // FFT buffers; the [P][17] tile aliases them
+    static_assert(BUF >= P * kTilePitch, "the transpose tile must fit the FFT buffers it aliases");
+    static constexpr size_t lds(int twn) { return (size_t)(twn + BUF) * sizeof(float2); }
+    static constexpr int bpc(int twn) {                           // blocks per CU that LDS and the 32-wave limit allow
+        const int by_lds = (int)((160 * 1024) / lds(twn)), by_waves = 2048 / THREADS;
+        const int b = by_lds < by_waves ? by_lds : by_waves;
+        return b < 1 ? 1 : (b > 2 ? 2 : b);
+    }
+    static constexpr int waves_per_simd(int twn) { return (bpc(twn) * THREADS + 255) / 256; }
+};
+
+// K1: pack + pad + row FFT of 16 consecutive rows of one field, written transposed
+template <int P, bool PAD>
+__global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_entries_fwd<P>())) void asm_rows_fwd_t_kernel(
+    const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
+    float phase_scale, v2f* __restrict__ tbuf) {
+    using C = RowTCfg<P>;
+    constexpr int S = PAD ? P / 2 : P;
+    constexpr int G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
+    constexpr int R1 = fft_radix<P, -1>(0);
+    constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);
+    constexpr int TWN = tw_entries_fwd<P>();
+    static_assert(S % kTileRows == 0, "a block's 16 rows must belong to one field");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* tw = reinterpret_cast<v2f*>(smem_raw);
+    v2f* buf = tw + TWN;
+
+    const int tid = threadIdx.x;
+    const int seq = tid / G, t = tid % G;
+    const long row0 = (long)blockIdx.x * kTileRows;
+    const long f = row0 / S;
+    const int y0 = (int)(row0 % S);
+    v2f* my = buf + seq * PITCH;
+    fft_fill_twiddles<P, -1>(tw, tid, THREADS);
+
+    v2f v[E];
+    {
+        const int y = y0 + seq;
+        const long base0 = f * stride0 + (long)y * S, base1 = f * stride1 + (long)y * S;
+        // element index i = j + r*P/R1 with j < P/R1: the replicate-pad regions (Angular_Spectrum_Method.py:12) are
+        // whole r-slices.  Interior elements are loaded and packed first; the two edge values (columns 0 and S-1)
+        // are interior elements of the row's first / last lane, so they are broadcast instead of recomputed.
+        constexpr bool ONE_BFLY = (E == R1) && (G <= 64);
+        v2f edge0 = {0.f, 0.f}, edge1 = edge0;
+        if (PAD && !ONE_BFLY) {
+            edge0 = load_field(in0, in1, in_mode, base0, base1, phase_scale);
+            edge1 = load_field(in0, in1, in_mode, base0 + S - 1, base1 + S - 1, phase_scale);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r = e % R1;
+            const bool left = PAD && (r + 1) * 4 <= R1;
+            const bool right = PAD && r * 4 >= 3 * R1;
+            if (!left && !right) {
+                const int i = fft_elem_index<P, G, R1>(t, e);
+                const int col = PAD ? i - S / 2 : i;
+                v[e] = load_field(in0, in1, in_mode, base0 + col, base1 + col, phase_scale);
+            }
+        }
+        if (PAD && ONE_BFLY) {
+            const v2f lo = v[R1 / 4], hi = v[3 * R1 / 4 - 1];
+            edge0 = v2f{__shfl(lo.x, 0, G), __shfl(lo.y, 0, G)};
+            edge1 = v2f{__shfl(hi.x, G - 1, G), __shfl(hi.y, G - 1, G)};
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r = e % R1;
+            if (PAD && (r + 1) * 4 <= R1) v[e] = edge0;
+            if (PAD && r * 4 >= 3 * R1) v[e] = edge1;
+        }
+    }
+    __syncthreads();  // twiddle table
+    fft_run<P, G, -1>(v, my, tw, t);
+    __syncthreads();  // every row is done with its FFT buffer: the tile aliases them
+#pragma unroll
+    for (int e = 0; e < E; ++e) buf[fft_elem_index<P, G, RL>(t, e) * kTilePitch + seq] = v[e];
+    __syncthreads();
+    // T^T[f][kx][y0 .. y0+15]: one 128-B run per kx, 16 B per thread
+    v2f* dst = tbuf + ((long)f * P) * S + y0;
+    for (int q = tid; q < P * (kTileRows / 2); q += THREADS) {
+        const int kx = q / (kTileRows / 2), j = q % (kTileRows / 2);
+        const v2f a = buf[kx * kTilePitch + 2 * j], b = buf[kx * kTilePitch + 2 * j + 1];
+        *reinterpret_cast<float4*>(dst + (long)kx * S + 2 * j) = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+template <int P>
+struct ColTCfg {
+    static constexpr int G = FftGeom<P>::G, E = FftGeom<P>::E;
+    // columns are independent (no staging, no block barrier after the twiddle fill): small blocks, many per CU
+    static constexpr int THREADS = P * G < 256 ? P * G : 256;
+    static constexpr int CW = THREADS / G;
+    static constexpr int PITCH = fft_padded_len(P) + 1;
+    static constexpr int TWN = tw_entries_fwd<P>() + (fft_plan_symmetric<P>() ? 0 : tw_entries_inv<P>());
+    static constexpr size_t LDS = (size_t)(TWN + CW * PITCH) * sizeof(float2);
+    static constexpr int BPC_LDS = (int)((160 * 1024) / LDS);
+    static constexpr int BPC = BPC_LDS * THREADS > 2048 ? 2048 / THREADS : BPC_LDS;
+    static constexpr int WPS0 = (BPC * THREADS) / 256;
+    static constexpr int WAVES_PER_SIMD = WPS0 < 1 ? 1 : (WPS0 > 8 ? 8 : WPS0);
+    static_assert(P % CW == 0, "column groups must tile the transform side");
+};
+
+// K2: one column per G lanes, global -> registers -> global
+template <int P, bool PAD>
+__global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) void asm_cols_t_kernel(
+    const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const double* __restrict__ phase_const,
+    int n_dist, double inv_ppx, double lam2, double lamb, int ablate) {
+    using C = ColTCfg<P>;
+    constexpr int S = PAD ? P / 2 : P;
+    constexpr int CW = C::CW, G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
+    constexpr int R1 = fft_radix<P, -1>(0);
+    constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);  // forward's last = inverse's first radix
+    static_assert(fft_radix<P, +1>(0) == RL && fft_radix<P, +1>(FftPlan<P>::n - 1) == R1, "plan symmetry");
+    constexpr bool SYM = fft_plan_symmetric<P>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* twf = reinterpret_cast<v2f*>(smem_raw);
+    v2f* twi = SYM ? twf : twf + tw_entries_fwd<P>();
+    v2f* cols = twf + C::TWN;
+
+    const int tid = threadIdx.x;
+    const int fo = blockIdx.y;          // output field = field * n_dist + dist
+    const int f = fo / n_dist;
+    const int col = tid / G, t = tid % G;
+    const int kx = blockIdx.x * CW + col;
+    v2f* my = cols + col * PITCH;
+    fft_fill_twiddles<P, -1>(twf, tid, THREADS);
+    if (!SYM) fft_fill_twiddles<P, +1>(twi, tid, THREADS);
+
+    // the column's S values are contiguous; rows above/below the field are copies of its first/last row spectrum
+    const v2f* src = tbuf + ((long)f * P + kx) * S;
+    v2f v[E];
+    {
+        v2f edge0 = {0.f, 0.f}, edge1 = edge0;
+        if (PAD) {
+            edge0 = src[0];
+            edge1 = src[S - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r = e % R1;
+            const bool left = PAD && (r + 1) * 4 <= R1;
+            const bool right = PAD && r * 4 >= 3 * R1;
+            if (left) v[e] = edge0;
+            else if (right) v[e] = edge1;
+            else {
+                const int i = fft_elem_index<P, G, R1>(t, e);
+                v[e] = src[PAD ? i - S / 2 : i];
+            }
+        }
+    }
+    __syncthreads();  // twiddle tables: the only block barrier
+    if (!(ablate & 2)) fft_run<P, G, -1>(v, my, twf, t);   // spectrum in registers at ky = fft_elem_index<P,G,RL>(t,e)
+
+    // transfer function: one value per (column, |ky|), shared through LDS by rows ky and P-ky.  The column's
+    // LDS region is private to its G lanes (one wave or less): wave-local ordering, no block barrier.
+    fft_sync<G>();
+    {
+        // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
+        const double c_over_l = phase_const[fo] / lamb;
+        const double fx = (double)(kx < P / 2 ? kx : kx - P) * inv_ppx;
+        const double fx2 = fx * fx;
+        for (int m = t; m <= P / 2; m += G) {
+            const double fy = (double)m * inv_ppx;
+            my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
+        }
+    }
+    fft_sync<G>();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int ky = fft_elem_index<P, G, RL>(t, e);
+        v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
+    }
+    if (!(ablate & 2)) fft_run<P, G, +1>(v, my, twi, t);
+
+    // keep the S centre rows: contiguous runs of G values per register slot
+    v2f* dst = ubuf + ((long)fo * P + kx) * S;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int r = e % R1;
+        if (PAD && ((r + 1) * 4 <= R1 || r * 4 >= 3 * R1)) continue;
+        const int i = fft_elem_index<P, G, R1>(t, e);
+        dst[PAD ? i - S / 2 : i] = v[e];
+    }
+}
+
+// K3: 16 rows of one output field: transposed load, row IFFT, crop, epilogue
+template <int P, bool PAD>
+__global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_entries_inv<P>())) void asm_rows_inv_t_kernel(
+    const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode,
+    long ostride0, long ostride1, float scale) {
+    using C = RowTCfg<P>;
+    constexpr int S = PAD ? P / 2 : P;
+    constexpr int G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
+    constexpr int R1 = fft_radix<P, +1>(0);
+    constexpr int RL = fft_radix<P, +1>(FftPlan<P>::n - 1);
+    constexpr int TWN = tw_entries_inv<P>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* tw = reinterpret_cast<v2f*>(smem_raw);
+    v2f* buf = tw + TWN;
+
+    const int tid = threadIdx.x;
+    const int seq = tid / G, t = tid % G;
+    const long row0 = (long)blockIdx.x * kTileRows;
+    const long fo = row0 / S;
+    const int y0 = (int)(row0 % S);
+    v2f* my = buf + seq * PITCH;
+    fft_fill_twiddles<P, +1>(tw, tid, THREADS);
+    // U^T[fo][kx][y0 .. y0+15] -> tile[kx][row]
+    {
+        const v2f* src = ubuf + ((long)fo * P) * S + y0;
+        for (int q = tid; q < P * (kTileRows / 2); q += THREADS) {
+            const int kx = q / (kTileRows / 2), j = q % (kTileRows / 2);
+            const float4 d = *reinterpret_cast<const float4*>(src + (long)kx * S + 2 * j);
+            buf[kx * kTilePitch + 2 * j] = v2f{d.x, d.y};
+            buf[kx * kTilePitch + 2 * j + 1] = v2f{d.z, d.w};
+        }
+    }
+    __syncthreads();
+    v2f v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = buf[fft_elem_index<P, G, R1>(t, e) * kTilePitch + seq];
+    __syncthreads();  // the tile is consumed: its space becomes the rows' FFT buffers
+    fft_run<P, G, +1>(v, my, tw, t);
+    {
+        const int y = y0 + seq;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r = e % RL;
+            // centre crop (Angular_Spectrum_Method.py:34): with padding only the middle r-slices survive
+            if (PAD && ((r + 1) * 4 <= RL || r * 4 >= 3 * RL)) continue;
+            const int i = fft_elem_index<P, G, RL>(t, e);
+            const int x = PAD ? i - S / 2 : i;
+            const v2f o = v[e] * scale;
+            const long pix = (long)y * S + x;
+            if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
+                out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
+                out1[fo * ostride1 + pix] = atan2_poly(o.y, o.x);
+            } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
+                const float a = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
+                out0[fo * ostride0 + pix] = a * a;
+            } else {
+                reinterpret_cast<v2f*>(out0)[fo * ostride0 + pix] = o;
+            }
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 struct AsmArgs {
     const float *in0, *in1;
@@ -543,9 +810,46 @@ static int launch_asm(const AsmArgs& a) {
     return check_launch("holo_asm_propagate");
 }
 
+// transposed intermediates (32 <= P <= 1024, S % 16 == 0)
+template <int P, bool PAD>
+static int launch_asm_t(const AsmArgs& a) {
+    using R = RowTCfg<P>;
+    using C = ColTCfg<P>;
+    constexpr int S = PAD ? P / 2 : P;
+    const size_t row_lds_f = R::lds(tw_entries_fwd<P>()), row_lds_i = R::lds(tw_entries_inv<P>());
+    static unsigned long long attr_done = 0;  // per device
+    if (first_call_on_device(attr_done)) {
+        if (C::LDS > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_t_kernel<P, PAD>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        if (row_lds_f > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_t_kernel<P, PAD>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_f);
+        if (row_lds_i > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_t_kernel<P, PAD>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
+    }
+    const long blocks_in = (long)a.n_fields * S / kTileRows;
+    hipLaunchKernelGGL((asm_rows_fwd_t_kernel<P, PAD>), dim3((unsigned)blocks_in), dim3(R::THREADS), row_lds_f, a.stream,
+                       a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf));
+    hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD>), dim3(P / C::CW, a.n_fields * a.n_dist), dim3(C::THREADS), C::LDS, a.stream,
+                       reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
+                       1.0 / a.ppx, a.lam2, a.lamb, a.ablate);
+    const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
+    hipLaunchKernelGGL((asm_rows_inv_t_kernel<P, PAD>), dim3((unsigned)(blocks_in * a.n_dist)), dim3(R::THREADS), row_lds_i,
+                       a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0, a.os1, scale);
+    return check_launch("holo_asm_propagate");
+}
+
 template <int P>
 static int launch_asm_pad(const AsmArgs& a, bool pad) {
-    return pad ? launch_asm<P, true>(a) : launch_asm<P, false>(a);
+    if constexpr (P >= 32 && P <= 1024) {
+        return pad ? launch_asm_t<P, true>(a) : launch_asm_t<P, false>(a);
+    } else if constexpr (P == 16) {
+        return pad ? launch_asm<P, true>(a) : launch_asm_t<P, false>(a);   // S = 8 rows cannot fill a 16-row tile
+    } else {
+        return pad ? launch_asm<P, true>(a) : launch_asm<P, false>(a);
+    }
 }
 
 // ---- generic sizes: direct DFT ------------------------------------------------------------------------------

@@ -94,21 +94,37 @@ def compile_plan(children):
 class Plan:
     """Executable plan of one child list; owns the packed-weight cache."""
 
-    def __init__(self, children, dtype=torch.float32):
+    def __init__(self, children, dtype=torch.float32, conv_algo="auto"):
         self.steps = compile_plan(list(children))
         self.dtype = dtype          # activation / packed-weight dtype: float32 (exact fp32 MFMA), bfloat16, or ops.F32S
+        self.conv_algo = conv_algo  # fp32 3x3 layers: "direct" (implicit GEMM), "winograd" (F(2x2,3x3)), "auto" (by size)
         self._packed = {}
 
-    def _weights(self, idx, step):
+    # Winograd blocks are 32 x 16 pixels x 32 channels, one per CU: below ~2 blocks per CU (the bundled 5 x 128x128
+    # batches) the direct kernel's smaller tiles fill the chip better
+    WINO_MIN_BLOCKS = 512
+
+    def _use_winograd(self, step, x):
+        if self.dtype != torch.float32 or step.kind != "conv" or self.conv_algo == "direct":
+            return False
+        if self.conv_algo == "winograd":
+            return True
+        b, h, w, _ = x.shape
+        return b * ((h + 31) // 32) * ((w + 15) // 16) * (step.conv.out_channels // 32) >= self.WINO_MIN_BLOCKS
+
+    def _weights(self, idx, step, wino=False):
         conv = step.conv
         key = tuple(v for m in (conv, step.conv0) if m is not None
                     for v in (m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()))
+        idx = (idx, "wino") if wino else idx
         hit = self._packed.get(idx)
         if hit is not None and hit[0] == key:
             return hit[1]
         w = conv.weight.detach()
         b = conv.bias.detach().float().contiguous()
-        if step.kind == "conv":
+        if step.kind == "conv" and wino:
+            vals = (ops.pack_conv3x3_wino(w), b)
+        elif step.kind == "conv":
             vals = (ops.pack_conv3x3(w, self.dtype), b)
         elif step.kind == "convt":
             vals = (ops.pack_convt2x2(w, self.dtype), b)
@@ -134,6 +150,9 @@ class Plan:
 
     def run_step(self, idx, x):
         st = self.steps[idx]
+        if st.kind == "conv" and x.dtype == torch.float32 and self._use_winograd(st, x):
+            wts = self._weights(idx, st, wino=True)
+            return ops.conv3x3_wino(x, wts[0], wts[1], st.conv.out_channels, st.relu, st.pool)
         wts = self._weights(idx, st)
         if st.kind == "first":
             if x.dim() != 4 or x.shape[1] != 1:
@@ -186,11 +205,20 @@ class HoloSequential(nn.Sequential):
         self.invalidate_packed_weights()
         return out
 
+    def set_conv_algo(self, algo):
+        """fp32 3x3 layers: "auto" (default: Winograd F(2x2,3x3) where the layer fills the chip, else the direct
+        implicit-GEMM kernel), "direct" or "winograd".  Both are exact fp32 arithmetic; they differ by rounding only."""
+        if algo not in ("auto", "direct", "winograd"):
+            raise ValueError(f"conv algo must be 'auto', 'direct' or 'winograd', got {algo!r}")
+        object.__setattr__(self, "_holo_algo", algo)
+        return self
+
     def _plan(self):
         dtype = getattr(self, "_holo_dtype", torch.float32)
-        sig = (tuple(id(m) for m in self), dtype)
+        algo = getattr(self, "_holo_algo", "auto")
+        sig = (tuple(id(m) for m in self), dtype, algo)
         if getattr(self, "_holo_plan_sig", None) != sig:
-            object.__setattr__(self, "_holo_plan", Plan(list(self), dtype))
+            object.__setattr__(self, "_holo_plan", Plan(list(self), dtype, algo))
             object.__setattr__(self, "_holo_plan_sig", sig)
         return self._holo_plan
 

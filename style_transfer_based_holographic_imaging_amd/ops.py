@@ -219,6 +219,17 @@ def pack_conv3x3(w_oihw: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     return out
 
 
+def pack_conv3x3_wino(w_oihw: torch.Tensor) -> torch.Tensor:
+    """(Cout,Cin,3,3) -> the transformed weights G g G^T of the fp32 Winograd F(2x2,3x3) kernel."""
+    _req(w_oihw)
+    cout, cin, kh, kw = w_oihw.shape
+    assert (kh, kw) == (3, 3)
+    w = _f32c(w_oihw.detach())
+    out = torch.empty(lib.holo_conv3x3_wino_packed_elems(cout, cin), dtype=torch.float32, device=w.device)
+    _launch("holo_pack_conv3x3_wino_weight_f32", lambda: lib.holo_pack_conv3x3_wino_weight_f32(w.data_ptr(), out.data_ptr(), cout, cin, _stream()))
+    return out
+
+
 def pack_convt2x2(w_iohw: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
     _req(w_iohw)
     cin, cout, kh, kw = w_iohw.shape
@@ -262,6 +273,22 @@ def conv3x3(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, co
     _launch(name, lambda: getattr(lib, name)(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w,
                                              cin, cout, int(relu), int(pool), _stream()),
             flops=2.0 * 9 * cin * cout * b * h * w, nbytes=float(es) * b * (h * w * cin + ho * wo * cout))
+    return y
+
+
+def conv3x3_wino(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, relu=True, pool=False):
+    """conv3x3 as fp32 Winograd F(2x2,3x3) (weights from pack_conv3x3_wino).  FLOP are counted as the direct
+    convolution's (the algorithmic work), so a rate above the fp32 MFMA peak is the algorithm's gain."""
+    _req(x_nhwc, w_packed, bias)
+    b, h, w, cin = x_nhwc.shape
+    if x_nhwc.dtype != torch.float32 or w_packed.dtype != torch.float32:
+        raise RuntimeError("the Winograd kernel is fp32 only")
+    x_nhwc = _actc(x_nhwc)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+    y = torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x_nhwc.device)
+    _launch("holo_conv3x3_wino_f32", lambda: lib.holo_conv3x3_wino_f32(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                                     b, h, w, cin, cout, int(relu), int(pool), _stream()),
+            flops=2.0 * 9 * cin * cout * b * h * w, nbytes=4.0 * b * (h * w * cin + ho * wo * cout))
     return y
 
 

@@ -1,0 +1,154 @@
+"""GPU parity of the fp32 Winograd F(2x2,3x3) convolution (csrc/conv_winograd.hip) through the C-ABI: against a plain
+torch-CPU fp32 reference and a float64 evaluation of the same op, next to the direct implicit-GEMM kernel; then the whole
+network with every large 3x3 layer on the Winograd kernel against the oracle and against float64 truth."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import REPO, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from style_transfer_based_holographic_imaging_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from hip_helpers import DEV
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return DEV
+
+
+def _case(seed, b, h, w, cin, cout, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, cin, h, w, generator=g) * scale
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    return x, wt, bias
+
+
+def _ref(x, wt, bias, relu, pool):
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), wt, bias)
+    if relu:
+        ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
+    return ref
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,relu,pool", [
+    (2, 32, 16, 16, 32, True, False),      # exactly one block tile
+    (1, 8, 16, 64, 128, True, False),
+    (3, 13, 21, 32, 64, True, True),       # odd sizes: partial tiles, odd edge tiles + ceil_mode pooling
+    (2, 5, 5, 128, 256, True, True),
+    (1, 2, 2, 16, 64, False, False),       # smallest legal reflection-padded image, no ReLU
+    (2, 40, 24, 64, 64, True, True),
+    (1, 33, 47, 256, 128, True, False),
+    (2, 16, 16, 512, 512, True, False),
+    (1, 70, 35, 64, 96, False, False),     # Cout a multiple of 32 only; three tile rows, partial last ones
+    (1, 64, 64, 16, 32, True, True),       # one 16-channel chunk: prologue and epilogue only
+])
+def test_conv3x3_winograd(ops, dev, b, h, w, cin, cout, relu, pool):
+    x, wt, bias = _case(h * 1000 + w + cin, b, h, w, cin, cout)
+    ref = _ref(x, wt, bias, relu, pool)
+    ref64 = _ref(x.double(), wt.double(), bias.double(), relu, pool)
+    xp = ops.to_nhwc(x.to(dev))
+    y = ops.conv3x3_wino(xp, ops.pack_conv3x3_wino(wt.to(dev)), bias.to(dev), cout, relu, pool)
+    got = ops.as_nchw_view(y).cpu()
+    assert got.shape == ref.shape
+    # transforms add a few fp32 roundings to each product; the accumulation chain is Cin long instead of 9*Cin
+    assert rel_err(got, ref) < (6e-6 if cin >= 512 else 3e-6)
+    if cout % 64 == 0:
+        direct = ops.as_nchw_view(ops.conv3x3(xp, ops.pack_conv3x3(wt.to(dev)), bias.to(dev), cout, relu, pool)).cpu()
+        e_w, e_d = rel_err(got, ref64), rel_err(direct, ref64)
+        assert e_w < 4 * e_d + 1e-7, f"Winograd {e_w:.2e} vs direct {e_d:.2e} against float64"
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 1e3])
+def test_conv3x3_winograd_scales(ops, dev, scale):
+    """relative accuracy does not depend on the activation scale (no fixed-point assumption anywhere)"""
+    x, wt, bias = _case(5, 1, 24, 40, 64, 64, scale)
+    ref64 = _ref(x.double(), wt.double(), bias.double() * scale, True, False)
+    y = ops.conv3x3_wino(ops.to_nhwc(x.to(dev)), ops.pack_conv3x3_wino(wt.to(dev)), (bias * scale).to(dev), 64, True, False)
+    assert rel_err(ops.as_nchw_view(y).cpu(), ref64) < 2e-6
+
+
+def test_packed_winograd_weights_are_g_w_gt(ops, dev):
+    g = torch.Generator().manual_seed(1)
+    wt = torch.randn(64, 32, 3, 3, generator=g)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    U = (G @ wt.double() @ G.T).float()                                   # (co, ci, 4, 4)
+    packed = ops.pack_conv3x3_wino(wt.to(dev)).cpu().view(2, 2, 16, 32, 16)   # [co/32][ci/16][pos][co%32][ci%16]
+    want = U.view(2, 32, 2, 16, 16).permute(0, 2, 4, 1, 3)                # co_hi, ci_hi, pos, co_lo, ci_lo
+    assert torch.equal(packed, want.contiguous())
+
+
+def test_validation_winograd():
+    import ctypes
+    from style_transfer_based_holographic_imaging_amd._lib import lib
+    fake = ctypes.c_void_p(16)
+    assert lib.holo_conv3x3_wino_f32(None, fake, fake, fake, 1, 4, 4, 16, 32, 1, 0, None) == 1
+    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 24, 32, 1, 0, None) == 2     # Cin % 16
+    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 16, 48, 1, 0, None) == 2     # Cout % 32
+    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 16, 32, 0, 1, None) == 2     # pool without relu
+    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 1, 4, 16, 32, 1, 0, None) == 1     # H < 2
+    assert lib.holo_conv3x3_wino_packed_elems(128, 64) == 16 * 64 * 128
+
+
+@pytest.fixture(scope="module")
+def net_and_inputs(dev):
+    from hip_helpers import build_network, orc
+    from style_transfer_based_holographic_imaging_amd import synth
+    network, sds = build_network(0)
+    style = torch.load(os.path.join(REPO, "style_representation", "MNIST", "style_vector.pt"), map_location="cpu").float()
+    hp = orc.HoloParams()
+    ph = synth.synthetic_phase_objects(2, 96, seed=11)
+    d_c = synth.synthetic_distances(2, seed=11)
+    with torch.no_grad():
+        content = torch.sqrt(orc.holo_generator(hp, torch.full_like(ph, 0.6), ph, d_c)).float()
+    return network, sds, style, content
+
+
+def test_whole_network_on_winograd(net_and_inputs, dev):
+    """every 3x3 layer the MFMA kernels cover on the Winograd kernel: the graded outputs keep the 1e-4 bar against the CPU
+    oracle with the same margin as the direct kernel, and sit as close to a float64 evaluation as the direct path"""
+    from hip_helpers import orc
+    from utils.functions import field_retrieval
+    network, sds, style, content = net_and_inputs
+    dbl = [{k: v.double() for k, v in sd.items()} for sd in sds]
+    with torch.no_grad():
+        want = orc.net_field_retrieval(content, style, *sds, 1.0, True)
+        truth = orc.net_field_retrieval(content.double(), style.double(), *dbl, 1.0, True)
+        outs = {}
+        for algo in ("direct", "winograd"):
+            network.set_conv_algo(algo)
+            outs[algo] = [t.cpu() for t in field_retrieval(network, content.to(dev), style.to(dev), 1.0, True)]
+        network.set_conv_algo("auto")
+    for name, i in (("amplitude", 0), ("phase", 1), ("distance", 2)):
+        w, d = outs["winograd"][i].view(-1), outs["direct"][i].view(-1)
+        assert rel_err(w, want[i].reshape(-1)) < 1e-4 / 3, name
+        e_w, e_d = rel_err(w, truth[i].reshape(-1)), rel_err(d, truth[i].reshape(-1))
+        assert e_w < 3 * e_d + 1e-7, f"{name}: Winograd {e_w:.2e} vs direct {e_d:.2e} against float64"
+
+
+def test_auto_picks_winograd_only_for_layers_that_fill_the_chip(dev):
+    from style_transfer_based_holographic_imaging_amd.engine import Plan
+    import net
+    plan = Plan(list(net.decoder.children()))
+    conv = next(s for s in plan.steps if s.kind == "conv")
+    big = torch.empty(64, 32, 32, conv.conv.in_channels, device="meta")
+    small = torch.empty(5, 16, 16, conv.conv.in_channels, device="meta")
+    assert plan._use_winograd(conv, big) and not plan._use_winograd(conv, small)
+    plan.conv_algo = "direct"
+    assert not plan._use_winograd(conv, big)
+    plan.conv_algo = "winograd"
+    assert plan._use_winograd(conv, small)
+    plan.dtype = torch.bfloat16
+    assert not plan._use_winograd(conv, big)

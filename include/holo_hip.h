@@ -79,7 +79,7 @@ int holo_conv3x3_f32(const float* x_nhwc, const float* w_packed, const float* bi
  * Winograd F(2x2,3x3) in exact fp32 arithmetic on the fp32 matrix cores: 2.25x fewer multiplications; results differ
  * from holo_conv3x3_f32 by fp32 rounding only (both ~1e-5 of the network's outputs away from a float64 evaluation).
  * Weights: (Cout,Cin,3,3) -> G g G^T (float64, rounded once) as [Cout/32][Cin/16][4x4 position][32][16] fp32,
- * 16*Cout*Cin floats.  Cin % 16 == 0, Cout % 32 == 0; shapes and flags as holo_conv3x3_f32. */
+ * 16*Cout*Cin floats.  Cin % 16 == 0 and Cin >= 32, Cout % 32 == 0; shapes and flags as holo_conv3x3_f32. */
 int holo_pack_conv3x3_wino_weight_f32(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
 size_t holo_conv3x3_wino_packed_elems(int cout, int cin);
 int holo_conv3x3_wino_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc,

@@ -27,11 +27,33 @@
 // accumulators), bias, ReLU, optional 2x2 max-pool (= exactly one Winograd tile), NHWC stores of 128-B runs.
 #include "common.h"
 
+#ifndef WINO_ABL
+#define WINO_ABL 0   // timing experiments only (-DWINO_ABL=n side builds; wrong results): 1 no epilogue stores, 2 no re-zeroing, 4 plan not rebuilt, 8 one tile per block
+#endif
+
+#ifndef WINO_STAMPS
+#define WINO_STAMPS 0   // profiling build only (scripts/wino_stamps.py): cycle stamps of block 0 / thread 0 per phase
+#endif
+
 namespace holo {
+
+#if WINO_STAMPS
+__device__ unsigned long long wino_dbg[16];
+#define WSTAMP(i_)                                                        \
+    {                                                                     \
+        const unsigned long long now_ = __builtin_readcyclecounter();     \
+        if (blockIdx.x == 0 && tid == 0) wino_dbg[i_] += now_ - t_last;   \
+        t_last = now_;                                                    \
+    }
+#else
+#define WSTAMP(i_)
+#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace wino {
+struct TrueC { static constexpr bool value = true; };
+struct FalseC { static constexpr bool value = false; };
 constexpr int kThreads = 256;
 constexpr int kTW = 8, kTH = 16;                 // tiles per block: 8 across, 16 down (4 per wave)
 constexpr int kPW = 2 * kTW, kPH = 2 * kTH;      // 16 x 32 output pixels
@@ -43,7 +65,8 @@ constexpr int kABytes = ((kSlots * 64 + 1023) / 1024) * 1024;   // 39936, rounde
 constexpr int kTN = 32;                          // output channels per block
 constexpr int kBBytes = 16 * kTN * 64;           // 32 KB: [pos][co][16 ch]
 constexpr int kBRounds = kBBytes / 16 / kThreads;   // 8
-constexpr int kLdsBytes = 2 * kABytes + 2 * kBBytes;   // 145408
+constexpr int kPlanBytes = kARounds * kThreads * 4;    // per-thread halo source offsets, kept in LDS (see make_plan)
+constexpr int kLdsBytes = 2 * kABytes + 2 * kBBytes + kPlanBytes;   // 155648
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 // halo pixel (hy, hx) -> 64-byte slot: even and odd columns of a row in separate runs, so that the 8 tiles of a tile
@@ -67,7 +90,7 @@ __device__ __forceinline__ int slot_of(int hy, int hx) { return hy * kHW + (hx &
 
 __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
-    int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int relu, int pool) {
+    int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int total, int relu, int pool) {
     using namespace wino;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_a = smem;                  // [2][kABytes]
@@ -76,58 +99,73 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n_blk = Cout / kTN;
-    int bid = blockIdx.x;
-    // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): a contiguous range of blocks per XCD, so that the
-    // channel blocks of one patch (same halo) and neighbouring patches meet in one L2.  Bijective when the grid is a
-    // multiple of 8; speed only.
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-    const int nb = bid % n_blk;
-    bid /= n_blk;
-    const int txb = bid % tiles_x;
-    bid /= tiles_x;
-    const int tyb = bid % tiles_y;
-    const int img = bid / tiles_y;
-    const int y0 = tyb * kPH, x0 = txb * kPW;
-    const int n0 = nb * kTN;
-    const float* __restrict__ ximg = x + (size_t)img * H * W * Cin;
     const int nchunks = Cin / 16;
+
+    // ---- tiles ----------------------------------------------------------------------------------------------------
+    // The grid is PERSISTENT: block b works on tiles b, b + gridDim.x, ... (one block per CU: 512 registers per lane).  A
+    // tile's fixed costs — the latency of its first halo/weight loads, the staging plan, zeroing 256 accumulators, a block
+    // launch — were ~10 us against 14 us of MFMA work for the 64-channel layers; here the next tile's first chunk is
+    // requested during the current tile's last chunk and the first MFMA of a tile takes C = 0.
+    // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): XCD c gets a contiguous range of tile ids, so that
+    // the channel blocks of one patch (same halo) and neighbouring patches meet in one L2 at about the same time.
+    // Bijective when the tile count is a multiple of 8; speed only.
+    struct Tile { int nb, img, y0, x0; };
+    auto decode = [&](int vb) {
+        int bid = vb;
+        if ((total & 7) == 0) bid = (vb & 7) * (total >> 3) + (vb >> 3);
+        Tile t;
+        t.nb = bid % n_blk;
+        bid /= n_blk;
+        t.x0 = (bid % tiles_x) * kPW;
+        bid /= tiles_x;
+        t.y0 = (bid % tiles_y) * kPH;
+        t.img = bid / tiles_y;
+        return t;
+    };
 
     // ---- staging plans ------------------------------------------------------------------------------------------
     // LDS unit U = tid + 256 r of the halo image = unit u' of slot U>>2; it holds logical unit u' ^ ((hy>>1)&3) of that pixel
-    unsigned a_src[kARounds];
+    // The plan lives in LDS, not in registers: with 256 accumulators + two patches there is no room for 10 more VGPRs, and a
+    // spilled offset is reloaded with scratch_load + s_waitcnt vmcnt(0) right in front of its DMA — which also waits for
+    // every LDS-DMA in flight and serialised the whole staging pipeline (135 instead of 265 TFLOP/s when that happened).
+    // Each thread reads back only what it wrote itself: no barrier needed.
+    unsigned* plan = reinterpret_cast<unsigned*>(smem + 2 * kABytes + 2 * kBBytes) + tid;
+    auto make_plan = [&](const Tile& t) {
+        // The thread index is made opaque here on purpose: otherwise hipcc hoists the tile-independent half of the plan (30
+        // per-thread values) out of the persistent loop, spills it, and reloads it per tile with 30 serialised
+        // scratch_load + s_waitcnt vmcnt(0) pairs: ~24 us per tile, more than a 64-channel tile's MFMA time.  Recomputing
+        // costs ~350 VALU instructions per tile.
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
 #pragma unroll
-    for (int r = 0; r < kARounds; ++r) {
-        int U = tid + r * kThreads;
-        U = U < kAUnits ? U : kAUnits - 1;        // the partial round is masked at issue; keep the address valid anyway
-        const int s = U >> 2, up = U & 3;
-        const int hy = s / kHW, rem = s % kHW;
-        const int hx = rem < kHW / 2 ? 2 * rem : 2 * (rem - kHW / 2) + 1;
-        const int u = up ^ ((hy >> 1) & 3);
-        const int ry = reflect1(y0 - 1 + hy, H), rx = reflect1(x0 - 1 + hx, W);
-        a_src[r] = (unsigned)((ry * W + rx) * Cin + 4 * u) * 4u;    // byte offset within the image (< 2^32: entry check)
-    }
+        for (int r = 0; r < kARounds; ++r) {
+            int U = tid_o + r * kThreads;
+            U = U < kAUnits ? U : kAUnits - 1;        // the partial round is masked at issue; keep the address valid anyway
+            const int s = U >> 2, up = U & 3;
+            const int hy = s / kHW, rem = s % kHW;
+            const int hx = rem < kHW / 2 ? 2 * rem : 2 * (rem - kHW / 2) + 1;
+            const int u = up ^ ((hy >> 1) & 3);
+            const int ry = reflect1(t.y0 - 1 + hy, H), rx = reflect1(t.x0 - 1 + hx, W);
+            plan[r * kThreads] = (unsigned)((ry * W + rx) * Cin + 4 * u) * 4u;    // byte offset within the image (< 2^32: entry check)
+        }
+    };
     // weight tile of a chunk: [pos][co][16 ch], contiguous 32 KB in the packed tensor; LDS unit U = row*4 + u' holds
     // logical unit u' ^ ((co>>2)&3) of row (pos, co)
-    unsigned b_src[kBRounds];
-#pragma unroll
-    for (int r = 0; r < kBRounds; ++r) {
-        const int U = tid + r * kThreads;
-        const int row = U >> 2, up = U & 3;
-        const int u = up ^ ((row >> 2) & 3);      // row = pos*32 + co: (row>>2)&3 == (co>>2)&3
-        b_src[r] = (unsigned)(row * 64 + u * 16);
-    }
+    // Round r covers rows (tid>>2) + 64 r: the key ((row>>2)&3) does not depend on r, so one per-lane offset serves all
+    // rounds and round r adds 4096 bytes to the wave-uniform base.
+    const unsigned b_src0 = (unsigned)((tid >> 2) * 64 + (((tid & 3) ^ ((tid >> 4) & 3)) << 4));
     const int wave_base = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
     const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
-    const float* __restrict__ wblk = wp + (size_t)nb * nchunks * (kBBytes / 4);   // [nb][chunk][pos][co][16]
 
-#define WINO_LOAD_A_ROUND(chunk_, buf_, r_)                                                                     \
+#define WINO_LOAD_A_ROUND(abase_, buf_, r_, off_)                                                               \
     if ((r_) < kARounds - 1 || tid + (r_) * kThreads < kAUnits)                                                 \
-        WINO_GLDS16_S(ximg + (chunk_) * 16, a_src[r_], (buf_) * kABytes + (r_) * kThreads * 16 + wave_base)
-#define WINO_LOAD_B_ROUND(chunk_, buf_, r_)                                                                     \
-    WINO_GLDS16_S(wblk + (size_t)(chunk_) * (kBBytes / 4), b_src[r_], 2 * kABytes + (buf_) * kBBytes + (r_) * kThreads * 16 + wave_base)
+        WINO_GLDS16_S(abase_, off_, (buf_) * kABytes + (r_) * kThreads * 16 + wave_base)
+#define WINO_LOAD_B_ROUND(bbase_, buf_, r_)                                                                     \
+    WINO_GLDS16_S((bbase_) + (r_) * (kThreads * 16 / 4), b_src0, 2 * kABytes + (buf_) * kBBytes + (r_) * kThreads * 16 + wave_base)
 
     // ---- per-lane operand coordinates ---------------------------------------------------------------------------
     const int hsel = lane >> 5, li = lane & 31;
+    const int hsel_ = hsel, li_ = li, wave_ = wave;        // (the epilogue shadows these with opaque copies)
     const int ltx = li & 7, lty = li >> 3;                 // tile within the wave's 4 x 8 tiles
     const int hy0 = 2 * (4 * wave + lty);                  // halo row of the patch's first row (halo origin = y0-1)
     // patch pixel (i, j): slot = (hy0+i)*18 + (j&1)*9 + ltx + (j>>1); unit key = ((hy0+i)>>1)&3 = (lty + (i>>1)) & 3
@@ -137,130 +175,305 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     const int bkey = (li >> 2) & 3;
 
     floatx16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
-    // B^T d B of this lane's tile for the channel quad (2*jj + hsel) of the chunk in halo buffer `abuf_`
-    auto transform_in = [&](const unsigned char* abuf, int jj, float4 (&V)[16]) {
-        const int u = 2 * jj + hsel;
-        float4 t[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 d[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int off = a_base + (i * kHW + (j & 1) * (kHW / 2) + (j >> 1)) * 64 + ((u ^ (i < 2 ? key0 : key1)) << 4);
-                d[i] = *reinterpret_cast<const float4*>(abuf + off);
-            }
-            // rows of B^T: [1,0,-1,0], [0,1,1,0], [0,-1,1,0], [0,1,0,-1]
-            t[0][j] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
-            t[1][j] = make_float4(d[1].x + d[2].x, d[1].y + d[2].y, d[1].z + d[2].z, d[1].w + d[2].w);
-            t[2][j] = make_float4(d[2].x - d[1].x, d[2].y - d[1].y, d[2].z - d[1].z, d[2].w - d[1].w);
-            t[3][j] = make_float4(d[1].x - d[3].x, d[1].y - d[3].y, d[1].z - d[3].z, d[1].w - d[3].w);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 a = t[i][0], b = t[i][1], c = t[i][2], e = t[i][3];
-            V[4 * i + 0] = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
-            V[4 * i + 1] = make_float4(b.x + c.x, b.y + c.y, b.z + c.z, b.w + c.w);
-            V[4 * i + 2] = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);
-            V[4 * i + 3] = make_float4(b.x - e.x, b.y - e.y, b.z - e.z, b.w - e.w);
-        }
+    // ---- software-pipelined step -----------------------------------------------------------------------------------------
+    // One step = 16 positions x 4 MFMAs (64 MFMAs, 4096 cycles) on the transformed patch V of one channel quad per lane half.
+    // Everything else is cut into 16 slices that ride in the shadow of the previous slice's MFMAs:
+    //   * the weight fragment of position p+1 is read from LDS before the MFMAs of position p are issued;
+    //   * B^T d B of the NEXT quarter's patch: slices 0-3 transform patch column p (rows of B^T) from d values read one slice
+    //     earlier, slices 4-7 transform row p-4 (columns);
+    //   * LDS-DMA rounds of the next chunk's halo or weights, two per slice from the first slice on.
+    // LDS read latency (~100+ cycles) would otherwise be exposed once per position: the first version of this kernel read
+    // each fragment right before its use and reached 58 % of the matrix pipe.  (With channel pairs instead of quads — half
+    // the patch registers, 32 MFMAs per step — a slice's 128 MFMA cycles no longer cover that latency: 150 instead of 260
+    // TFLOP/s.)
+    // kCW = channels per lane half and step: 4 (two steps of 64 MFMAs per chunk, ds_read_b128) or 2 (four steps of 32, ds_read_b64)
+    constexpr int kCW = 4;
+    constexpr int kSteps = 8 / kCW;                  // steps per chunk
+    typedef float vecw __attribute__((ext_vector_type(kCW)));
+    // step s of a chunk: lane half h takes channels 4*u + (kCW == 2 ? 2*(s&1) : 0) + {0..kCW-1} of 16-byte unit u = 2*(s*kCW/4) + h
+    auto unit_of = [&](int st) { return 2 * ((st * kCW) / 4) + hsel; };
+    auto sub_of = [&](int st) { return kCW == 2 ? (st & 1) * 8 : 0; };
+    auto read_b = [&](const unsigned char* bbuf, int st, int p) {
+        return *reinterpret_cast<const vecw*>(bbuf + p * (kTN * 64) + b_base + ((unit_of(st) ^ bkey) << 4) + sub_of(st));
     };
-    // 64 MFMAs of one half-chunk: acc[pos] += V[pos] (4 channels) x weights(pos, same 4 channels)
-    auto mfma_pos = [&](const unsigned char* bbuf, int jj, int p, const float4 (&V)[16]) {
-        const float4 bv = *reinterpret_cast<const float4*>(bbuf + p * (kTN * 64) + b_base + (((2 * jj + hsel) ^ bkey) << 4));
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p].x, bv.x, acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p].y, bv.y, acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p].z, bv.z, acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p].w, bv.w, acc[p], 0, 0, 0);
+    auto read_d = [&](const unsigned char* abuf, int st, int j, vecw (&d)[4]) {
+        const int u = unit_of(st);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            d[i] = *reinterpret_cast<const vecw*>(abuf + a_base + (i * kHW + (j & 1) * (kHW / 2) + (j >> 1)) * 64 +
+                                                 ((u ^ (i < 2 ? key0 : key1)) << 4) + sub_of(st));
+    };
+    // rows of B^T: [1,0,-1,0], [0,1,1,0], [0,-1,1,0], [0,1,0,-1]
+    auto bt4 = [&](vecw a, vecw b, vecw c, vecw e, vecw& o0, vecw& o1, vecw& o2, vecw& o3) {
+        o0 = a - c;
+        o1 = b + c;
+        o2 = c - b;
+        o3 = b - e;
     };
     auto stage_sync = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs have landed
         __syncthreads();                                     // everybody's have; everybody is done reading the old buffers
     };
-
-    // ---- prologue -----------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < kARounds; ++r) { WINO_LOAD_A_ROUND(0, 0, r) }
-#pragma unroll
-    for (int r = 0; r < kBRounds; ++r) { WINO_LOAD_B_ROUND(0, 0, r) }
-    stage_sync();
-    float4 V0[16], V1[16];
-    transform_in(lds_a, 0, V0);
-
-    // ---- main loop: one chunk = two steps (channel quads 0-1, then 2-3, of each lane half) -----------------------
-    int par = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool more = chunk + 1 < nchunks;
-        const unsigned char* abuf = lds_a + par * kABytes;
-        const unsigned char* bbuf = lds_b + par * kBBytes;
-        // step 0: MFMAs on V0; meanwhile V1 = second half of this chunk; the next chunk's halo is requested
-        // (its buffer was released by the barrier that ended step 0 of the previous chunk)
-        transform_in(abuf, 1, V1);
+    // MFMAs of step st on V; transforms the patch of (tbuf, tst) into Vn;  dma (runtime, block-uniform): 0 none, 1 halo rounds
+    // from `gsrc` into halo buffer nbuf, 2 weight rounds from `gsrc` into weight buffer nbuf
+    auto step = [&](auto do_t_c, const unsigned char* bbuf, int st, const vecw (&V)[16], const unsigned char* tbuf, int tst,
+                    vecw (&Vn)[16], int dma, const float* gsrc, int nbuf) {
+        constexpr bool do_t = decltype(do_t_c)::value;   // false: no transform (a tile's last step: the next tile's first patch
+                                                         // is computed after the epilogue, so that it is not live across it)
+        vecw bv = read_b(bbuf, st, 0);
+        vecw dcur[4], t[4][4];
+        if constexpr (do_t) read_d(tbuf, tst, 0, dcur);
+        unsigned off0 = plan[0], off1 = plan[kThreads];   // halo source offsets of the rounds issued in the next slice
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            mfma_pos(bbuf, 0, p, V0);
-            if (more && p < kARounds) { WINO_LOAD_A_ROUND(chunk + 1, par ^ 1, p) }
+            vecw bn = bv;
+            if (p < 15) bn = read_b(bbuf, st, p + 1);
+            // One LDS-DMA instruction costs 60-185 issue cycles and an fp32 MFMA covers 64: the two rounds of a slice go
+            // behind its first and its third MFMA, never back to back (two in front of the slice's MFMAs left ~140 cycles
+            // per slice uncovered: 17 % of a step).
+            static_assert(kCW == 4, "DMA placement below assumes four MFMAs per position");
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][0], bv[0], acc[p], 0, 0, 0);
+            if (dma == 1 && 2 * p < kARounds) { WINO_LOAD_A_ROUND(gsrc, nbuf, 2 * p, off0) }
+            if (dma == 2 && 2 * p < kBRounds) { WINO_LOAD_B_ROUND(gsrc, nbuf, 2 * p) }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][1], bv[1], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][2], bv[2], acc[p], 0, 0, 0);
+            if (dma == 1 && 2 * p + 1 < kARounds) { WINO_LOAD_A_ROUND(gsrc, nbuf, 2 * p + 1, off1) }
+            if (dma == 2 && 2 * p + 1 < kBRounds) { WINO_LOAD_B_ROUND(gsrc, nbuf, 2 * p + 1) }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][3], bv[3], acc[p], 0, 0, 0);
+            if (2 * p + 2 < kARounds) off0 = plan[(2 * p + 2) * kThreads];
+            if (2 * p + 3 < kARounds) off1 = plan[(2 * p + 3) * kThreads];
+            if constexpr (do_t) {
+                if (p < 4) {
+                    bt4(dcur[0], dcur[1], dcur[2], dcur[3], t[0][p], t[1][p], t[2][p], t[3][p]);
+                    if (p < 3) read_d(tbuf, tst, p + 1, dcur);   // consumed one slice later: no second register set
+                }
+                if (p >= 4 && p < 8) {
+                    const int i = p - 4;
+                    bt4(t[i][0], t[i][1], t[i][2], t[i][3], Vn[4 * i + 0], Vn[4 * i + 1], Vn[4 * i + 2], Vn[4 * i + 3]);
+                }
+            }
+            bv = bn;
+            __builtin_amdgcn_sched_barrier(0);   // keep the slices in this order
         }
-        stage_sync();
-        // step 1: MFMAs on V1; meanwhile V0 = first half of the next chunk (its halo has just landed); the next
-        // chunk's weights are requested (their buffer was released by the barrier that ended the previous chunk)
-        if (more) transform_in(lds_a + (par ^ 1) * kABytes, 0, V0);
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            mfma_pos(bbuf, 1, p, V1);
-            if (more && p < kBRounds) { WINO_LOAD_B_ROUND(chunk + 1, par ^ 1, p) }
-        }
-        stage_sync();
-        par ^= 1;
-    }
-
-    // ---- epilogue: Y = A^T M A, bias, ReLU, optional pool, NHWC store ---------------------------------------------
-    // lane: channel n0 + li; register r: tile m = (r&3) + 8*(r>>2) + 4*hsel of the wave's 32 (tile row m>>3, column m&7)
-    const int co = n0 + li;
-    const float bv = bias[co];
-    const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
-    float* __restrict__ yimg = y + (size_t)img * (pool ? (size_t)Ho * Wo : (size_t)H * W) * Cout;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
-        const int Y = y0 + 2 * (4 * wave + (m >> 3)), X = x0 + 2 * (m & 7);
-        // A^T = [[1,1,1,0],[0,1,-1,-1]]: rows first
-        float s[2][4];
+    };
+    // the whole transform at once (a tile's first patch)
+    auto transform_now = [&](const unsigned char* abuf, vecw (&V)[16]) {
+        vecw t[4][4], d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-            s[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+            read_d(abuf, 0, j, d);
+            bt4(d[0], d[1], d[2], d[3], t[0][j], t[1][j], t[2][j], t[3][j]);
         }
-        float o[2][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            o[a][0] = s[a][0] + s[a][1] + s[a][2] + bv;
-            o[a][1] = s[a][1] - s[a][2] - s[a][3] + bv;
+        for (int i = 0; i < 4; ++i) bt4(t[i][0], t[i][1], t[i][2], t[i][3], V[4 * i + 0], V[4 * i + 1], V[4 * i + 2], V[4 * i + 3]);
+    };
+
+    // ---- epilogue of one tile: Y = A^T M A, bias, ReLU, optional pool, NHWC store ----------------------------------
+    // lane: channel n0 + li; register r: tile m = (r&3) + 8*(r>>2) + 4*hsel of the wave's 32 (tile row m>>3, column m&7)
+    auto epilogue = [&](const Tile& tl) {
+        // lane coordinates made opaque: nothing of the epilogue's addressing may be hoisted out of the persistent loop (hoisted
+        // values are live across the MFMA loop, where every VGPR is taken, and come back as scratch reloads in front of the
+        // LDS-DMAs: s_waitcnt vmcnt(0) then serialises the staging pipeline)
+        int li = li_, hsel = hsel_, wave = wave_;
+        asm volatile("" : "+v"(li), "+v"(hsel), "+v"(wave));
+        const int co = tl.nb * kTN + li;
+        const float bv = bias[co];
+        const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+        float* __restrict__ yimg = y + (size_t)tl.img * (pool ? (size_t)Ho * Wo : (size_t)H * W) * Cout;
+        const bool full = tl.y0 + kPH <= H && tl.x0 + kPW <= W;
+        // A^T M A on whole accumulator tiles, ONE TILE AT A TIME.  The accumulators live in AGPRs and VALU instructions cannot
+        // read those: a tile used by the VALU is copied to 16 VGPRs first.  Walking register by register over all 16 positions
+        // (the natural loop) needs every tile in VGPRs at once — 256 registers on top of the next patch that is already live —
+        // and spilled ~600 registers inside the persistent loop.  Row i of the 4x4 positions: u0 = M_i0 + M_i1 + M_i2,
+        // u1 = M_i1 - M_i2 - M_i3 (columns of A), then o[0][.] += u (i = 0,1,2) and o[1][.] += (+,-,-) u (i = 1,2,3).
+        // The reads are explicit v_accvgpr_read with an AGPR-constrained operand: a plain VALU use would constrain the whole
+        // accumulator tile to the VGPR class for its entire live range, and the register allocator then shuffles tiles between
+        // the two files inside the MFMA loop.  The last MFMAs of the tile were issued before the step's closing barrier; the
+        // s_nops cover the 16-pass MFMA -> AGPR read hazard, which hipcc does not pad for an asm statement.
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        auto rd_tile = [&](const floatx16& t) {
+            floatx16 v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float e;
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(e) : "a"(t[r]));
+                v[r] = e;
+            }
+            return v;
+        };
+        floatx16 o00, o01, o10, o11;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            floatx16 u0 = rd_tile(acc[4 * i + 0]);
+            floatx16 u1 = rd_tile(acc[4 * i + 1]);
+            u0 += u1;
+            {
+                const floatx16 m2 = rd_tile(acc[4 * i + 2]);
+                u0 += m2;
+                u1 -= m2;
+            }
+            u1 -= rd_tile(acc[4 * i + 3]);
+            if (i == 0) {
+                o00 = u0;
+                o01 = u1;
+            } else if (i == 1) {
+                o00 += u0;
+                o01 += u1;
+                o10 = u0;
+                o11 = u1;
+            } else if (i == 2) {
+                o00 += u0;
+                o01 += u1;
+                o10 -= u0;
+                o11 -= u1;
+            } else {
+                o10 -= u0;
+                o11 -= u1;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            const int Y = tl.y0 + 2 * (4 * wave + (m >> 3)), X = tl.x0 + 2 * (m & 7);
+            float o[2][2] = {{o00[r] + bv, o01[r] + bv}, {o10[r] + bv, o11[r] + bv}};
             if (relu) {
-                o[a][0] = fmaxf(o[a][0], 0.0f);
-                o[a][1] = fmaxf(o[a][1], 0.0f);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    o[a][0] = fmaxf(o[a][0], 0.0f);
+                    o[a][1] = fmaxf(o[a][1], 0.0f);
+                }
+            }
+            if (!pool) {
+                if (full) {   // the block's 32 x 16 pixels lie inside the image: no per-store bounds test (block-uniform)
+                    float* __restrict__ q = yimg + ((size_t)Y * W + X) * Cout + co;
+                    q[0] = o[0][0];
+                    q[Cout] = o[0][1];
+                    q[(size_t)W * Cout] = o[1][0];
+                    q[(size_t)W * Cout + Cout] = o[1][1];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            if (Y + a < H && X + b < W) yimg[((size_t)(Y + a) * W + (X + b)) * Cout + co] = o[a][b];
+                }
+            } else if (full) {
+                yimg[((size_t)(Y >> 1) * Wo + (X >> 1)) * Cout + co] = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
+            } else if (Y < H && X < W) {
+                // MaxPool2d(2,2,ceil_mode=True): the window is this tile; members beyond the image edge are left out
+                float mx = o[0][0];
+                if (X + 1 < W) mx = fmaxf(mx, o[0][1]);
+                if (Y + 1 < H) {
+                    mx = fmaxf(mx, o[1][0]);
+                    if (X + 1 < W) mx = fmaxf(mx, o[1][1]);
+                }
+                yimg[((size_t)(Y >> 1) * Wo + (X >> 1)) * Cout + co] = mx;
             }
         }
-        if (!pool) {
+    };
+
+    // ---- prologue: the block's first tile -----------------------------------------------------------------------
+    int vb = blockIdx.x;
+    Tile cur = decode(vb);
+    make_plan(cur);
+    const float* __restrict__ ximg = x + (size_t)cur.img * H * W * Cin;
+    const float* __restrict__ wblk = wp + (size_t)cur.nb * nchunks * (kBBytes / 4);   // [nb][chunk][pos][co][16]
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+    for (int r = 0; r < kARounds; ++r) { WINO_LOAD_A_ROUND(ximg, 0, r, plan[r * kThreads]) }
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    if (Y + a < H && X + b < W) yimg[((size_t)(Y + a) * W + (X + b)) * Cout + co] = o[a][b];
-        } else if (Y < H && X < W) {
-            // MaxPool2d(2,2,ceil_mode=True): the window is this tile; members beyond the image edge are left out
-            float mx = o[0][0];
-            if (X + 1 < W) mx = fmaxf(mx, o[0][1]);
-            if (Y + 1 < H) {
-                mx = fmaxf(mx, o[1][0]);
-                if (X + 1 < W) mx = fmaxf(mx, o[1][1]);
+    for (int r = 0; r < kBRounds; ++r) { WINO_LOAD_B_ROUND(wblk, 0, r) }
+    stage_sync();
+    vecw Va[16], Vb[16];
+    transform_now(lds_a, Va);
+
+    // ---- main loop over (tile, chunk); one chunk = kSteps steps -----------------------------------------------------------
+    // first step(s): MFMAs on Va; Vb = next step's patch; the next chunk's halo, then its weights, are requested (the halo
+    //     buffer was released by the barrier before the previous chunk's last step, the weight buffer by the one that ended it)
+    // barrier: the next halo has landed
+    // last step: MFMAs on the last patch; Va = first patch of the NEXT chunk
+    // barrier: the next weights have landed; this chunk's buffers are free.
+    // The "next chunk" of a tile's last chunk is chunk 0 of the block's next tile.  One flat loop over (tile, chunk).
+    // Accumulators are written (zeroed) and read (epilogue) through AGPR-constrained asm operands only, so that nothing but
+    // the MFMAs and those statements touches them: any VALU definition or use lets the register allocator move whole tiles to
+    // VGPRs, and inside the persistent loop it then kept all 16 there and copied them through one AGPR tile around every
+    // position's MFMAs (seen in the ISA: 16 v_accvgpr_write per 2 MFMAs, ~200 spilled registers).
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float z;
+                asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));
+                acc[p][r] = z;
             }
-            yimg[((size_t)(Y >> 1) * Wo + (X >> 1)) * Cout + co] = mx;
+        asm volatile("s_nop 1");   // v_accvgpr_write -> MFMA operand wait states (hipcc pads nothing around asm statements)
+    };
+    zero_acc();
+    int par = 0, c = 0;
+#if WINO_STAMPS
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+    for (;;) {
+        const bool is_last = c + 1 == nchunks;
+        bool has_more = true;
+        int vb_next = vb;
+        Tile nxt = cur;
+        const float* a_next = ximg + (c + 1) * 16;
+        const float* b_next = wblk + (size_t)(c + 1) * (kBBytes / 4);
+        if (is_last) {
+            vb_next = vb + (int)gridDim.x;
+            has_more = vb_next < total;
+#if WINO_ABL & 8
+            has_more = false;
+#endif
+            if (has_more) {
+                nxt = decode(vb_next);
+#if !(WINO_ABL & 4)
+                make_plan(nxt);
+#endif      // the current tile's plan issued its last round in q0 of the previous chunk
+                a_next = x + (size_t)nxt.img * H * W * Cin;
+                b_next = wp + (size_t)nxt.nb * nchunks * (kBBytes / 4);
+            }
         }
+        const unsigned char* abuf = lds_a + par * kABytes;
+        const unsigned char* bbuf = lds_b + par * kBBytes;
+        WSTAMP(4)   // loop top: decode + plan of the next tile on a tile's last chunk
+        static_assert(kSteps == 2, "the loop below is written for two steps per chunk");
+        step(TrueC{}, bbuf, 0, Va, abuf, 1, Vb, has_more ? 1 : 0, a_next, par ^ 1);
+        WSTAMP(0)
+        stage_sync();
+        WSTAMP(1)
+        // ONE instance of step 1 for every chunk (a second, transform-free instance for a tile's last chunk made the register
+        // allocator shuffle accumulators again): on a tile's last chunk the patch it computes is simply dropped — the next
+        // tile's first patch is recomputed behind the epilogue, so that no patch is live across it (64 VGPRs the epilogue's
+        // own four output tiles need: with them live the epilogue spilled and reloaded ~140 registers per tile, each reload
+        // followed by s_waitcnt vmcnt(0): 21 us per tile).
+        step(TrueC{}, bbuf, 1, Vb, lds_a + (par ^ 1) * kABytes, 0, Va, has_more ? 2 : 0, b_next, par ^ 1);
+        WSTAMP(2)
+        stage_sync();
+        WSTAMP(3)
+        par ^= 1;
+        if (!is_last) {
+            ++c;
+        } else {
+            epilogue(cur);
+            WSTAMP(5)
+            if (!has_more) break;
+#if !(WINO_ABL & 2)
+            zero_acc();
+#endif
+            cur = nxt;
+            vb = vb_next;
+            ximg = a_next;
+            wblk = b_next;
+            c = 0;
+            transform_now(lds_a + par * kABytes, Va);   // the next tile's first halo landed before this chunk's first barrier
+            WSTAMP(6)
+        }
+#if WINO_STAMPS
+        if (blockIdx.x == 0 && tid == 0) wino_dbg[is_last ? 8 : 7] += 1;
+#endif
     }
 }
 
@@ -299,6 +512,14 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
 
 }  // namespace holo
 
+#if WINO_STAMPS
+extern "C" void holo_wino_debug_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(holo::wino_dbg), sizeof(unsigned long long) * 16); }
+extern "C" void holo_wino_debug_reset(void) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(holo::wino_dbg), z, sizeof(z));
+}
+#endif
+
 extern "C" {
 
 size_t holo_conv3x3_wino_packed_elems(int cout, int cin) {
@@ -322,8 +543,8 @@ int holo_conv3x3_wino_f32(const float* x_nhwc, const float* w_packed, const floa
     HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc, HOLO_ERR_ARG, "holo_conv3x3_wino_f32: null pointer");
     HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG,
                  "holo_conv3x3_wino_f32: batch=%d h=%d w=%d (reflection padding needs h,w >= 2)", batch, h, w);
-    HOLO_REQUIRE(cin > 0 && cin % 16 == 0 && cout > 0 && cout % 32 == 0, HOLO_ERR_UNSUPPORTED,
-                 "holo_conv3x3_wino_f32: Cin=%d must be a multiple of 16 and Cout=%d of 32", cin, cout);
+    HOLO_REQUIRE(cin >= 32 && cin % 16 == 0 && cout > 0 && cout % 32 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_wino_f32: Cin=%d must be a multiple of 16 (at least 32) and Cout=%d a multiple of 32", cin, cout);
     HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_wino_f32: fused pooling requires relu");
     HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < (1L << 30), HOLO_ERR_UNSUPPORTED,
                  "holo_conv3x3_wino_f32: one image must stay below 2^30 elements (32-bit byte offsets)");
@@ -331,11 +552,26 @@ int holo_conv3x3_wino_f32(const float* x_nhwc, const float* w_packed, const floa
     const long blocks = (long)batch * tiles_x * tiles_y * (cout / wino::kTN);
     HOLO_REQUIRE(blocks > 0 && blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_wino_f32: grid of %ld blocks", blocks);
     static unsigned long long attr_done = 0;   // per device
-    if (first_call_on_device(attr_done))
+    static int n_cu[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (first_call_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, wino::kLdsBytes);
-    hipLaunchKernelGGL(conv_wino_f32_kernel, dim3((unsigned)blocks), dim3(wino::kThreads), wino::kLdsBytes, as_stream(stream),
-                       x_nhwc, w_packed, bias, y_nhwc, h, w, cin, cout, tiles_x, tiles_y, relu, pool);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (dev >= 0 && dev < 64) n_cu[dev] = cus;
+    }
+    // persistent grid: one block per CU (512 registers per lane, 142 KB of LDS), tiles dealt round-robin.  Every block
+    // runs to completion on its own (no inter-block waits), so a grid larger than the resident set would also be correct.
+    const int cus = (dev >= 0 && dev < 64 && n_cu[dev] > 0) ? n_cu[dev] : 256;
+#if WINO_ABL & 8
+    const long grid = blocks;
+#else
+    const long grid = blocks < cus ? blocks : cus;
+#endif
+    hipLaunchKernelGGL(conv_wino_f32_kernel, dim3((unsigned)grid), dim3(wino::kThreads), wino::kLdsBytes, as_stream(stream),
+                       x_nhwc, w_packed, bias, y_nhwc, h, w, cin, cout, tiles_x, tiles_y, (int)blocks, relu, pool);
     return check_launch("holo_conv3x3_wino_f32");
 }
 

@@ -105,7 +105,7 @@ class Plan:
     WINO_MIN_BLOCKS = 512
 
     def _use_winograd(self, step, x):
-        if self.dtype != torch.float32 or step.kind != "conv" or self.conv_algo == "direct":
+        if self.dtype != torch.float32 or step.kind != "conv" or self.conv_algo == "direct" or step.conv.in_channels < 32:
             return False
         if self.conv_algo == "winograd":
             return True

@@ -44,16 +44,17 @@ def _ref(x, wt, bias, relu, pool):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,relu,pool", [
-    (2, 32, 16, 16, 32, True, False),      # exactly one block tile
+    (2, 32, 16, 32, 32, True, False),      # exactly one block tile, two chunks (the minimum)
     (1, 8, 16, 64, 128, True, False),
     (3, 13, 21, 32, 64, True, True),       # odd sizes: partial tiles, odd edge tiles + ceil_mode pooling
     (2, 5, 5, 128, 256, True, True),
-    (1, 2, 2, 16, 64, False, False),       # smallest legal reflection-padded image, no ReLU
+    (1, 2, 2, 32, 64, False, False),       # smallest legal reflection-padded image, no ReLU
     (2, 40, 24, 64, 64, True, True),
     (1, 33, 47, 256, 128, True, False),
     (2, 16, 16, 512, 512, True, False),
     (1, 70, 35, 64, 96, False, False),     # Cout a multiple of 32 only; three tile rows, partial last ones
-    (1, 64, 64, 16, 32, True, True),       # one 16-channel chunk: prologue and epilogue only
+    (1, 64, 64, 32, 32, True, True),       # 8 tiles on a 256-block grid: one tile per block
+    (5, 96, 80, 32, 64, True, False),      # 150 tiles x 2 channel blocks: some persistent blocks run 2 tiles, some 1
 ])
 def test_conv3x3_winograd(ops, dev, b, h, w, cin, cout, relu, pool):
     x, wt, bias = _case(h * 1000 + w + cin, b, h, w, cin, cout)
@@ -94,11 +95,12 @@ def test_validation_winograd():
     import ctypes
     from style_transfer_based_holographic_imaging_amd._lib import lib
     fake = ctypes.c_void_p(16)
-    assert lib.holo_conv3x3_wino_f32(None, fake, fake, fake, 1, 4, 4, 16, 32, 1, 0, None) == 1
+    assert lib.holo_conv3x3_wino_f32(None, fake, fake, fake, 1, 4, 4, 32, 32, 1, 0, None) == 1
     assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 24, 32, 1, 0, None) == 2     # Cin % 16
-    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 16, 48, 1, 0, None) == 2     # Cout % 32
-    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 16, 32, 0, 1, None) == 2     # pool without relu
-    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 1, 4, 16, 32, 1, 0, None) == 1     # H < 2
+    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 16, 32, 1, 0, None) == 2     # Cin < 32 (two chunks)
+    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 32, 48, 1, 0, None) == 2     # Cout % 32
+    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 4, 4, 32, 32, 0, 1, None) == 2     # pool without relu
+    assert lib.holo_conv3x3_wino_f32(fake, fake, fake, fake, 1, 1, 4, 32, 32, 1, 0, None) == 1     # H < 2
     assert lib.holo_conv3x3_wino_packed_elems(128, 64) == 16 * 64 * 128
 
 

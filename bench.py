@@ -97,7 +97,7 @@ def pmc_traffic(batch, size, dtype, distances):
     if prof.get("bench_args") or prof.get("source_hash") != _lib.lib.holo_source_hash().decode():
         return None, None, None
     label = f"profiles/{os.path.basename(PMC_PROFILE)}, collected on library {prof['source_hash'][:12]} (separate rocprofv3 --pmc passes)"
-    conv = prof.get("conv_mfma_hbm_bytes_per_launch_avg")
+    conv = prof.get("conv_wino_hbm_bytes_per_launch_avg") or prof.get("conv_mfma_hbm_bytes_per_launch_avg")
     asm = prof.get("asm_hbm_bytes_per_call")
     return (round(conv) if conv else None), (round(asm) if asm else None), label
 

@@ -23,8 +23,11 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
-CONV = "conv_mfma_kernel"
-ASM = ("asm_rows_fwd_kernel", "asm_cols_kernel", "asm_cols_persistent_kernel", "asm_rows_inv_kernel")
+# kernel-name prefixes -> keys of the output ("wino": the Winograd 3x3 kernel, the dominant one; "conv": the implicit-GEMM
+# kernel, which still runs the transposed convolutions and the small 3x3 layers)
+KEYS = (("conv_wino_f32_kernel", "wino"), ("conv_mfma_kernel", "conv"), ("asm_rows_fwd", "asm_rows_fwd"), ("asm_cols", "asm_cols"),
+        ("asm_rows_inv", "asm_rows_inv"))
+ASM = ("asm_rows_fwd", "asm_cols", "asm_rows_inv")
 
 
 def one_pass(counter, outdir, bench_args):
@@ -69,7 +72,7 @@ def main():
         rows = last_step(one_pass(counter, os.path.join(args.scratch, counter.lower()), args.bench_args))
         for _, name, val in rows:
             short = name.split("(")[0]
-            key = "conv" if CONV in short else next((k for k in ASM if k in short), None)
+            key = next((k for pre, k in KEYS if pre in short), None)
             if key is None:
                 continue
             r = res.setdefault(key, {"launches": {}, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
@@ -81,9 +84,10 @@ def main():
         n = max(r["launches"].values())
         out["kernels"][key] = {"launches_per_step": n, "hbm_read_bytes_per_step": r["FETCH_SIZE"],
                                "hbm_write_bytes_per_step": r["WRITE_SIZE"]}
-    if "conv" in out["kernels"]:
-        c = out["kernels"]["conv"]
-        out["conv_mfma_hbm_bytes_per_launch_avg"] = (c["hbm_read_bytes_per_step"] + c["hbm_write_bytes_per_step"]) / c["launches_per_step"]
+    for key, field in (("wino", "conv_wino_hbm_bytes_per_launch_avg"), ("conv", "conv_mfma_hbm_bytes_per_launch_avg")):
+        if key in out["kernels"]:
+            c = out["kernels"][key]
+            out[field] = (c["hbm_read_bytes_per_step"] + c["hbm_write_bytes_per_step"]) / c["launches_per_step"]
     asm = [v for k, v in out["kernels"].items() if k in ASM]
     if asm:
         out["asm_hbm_bytes_per_call"] = sum(v["hbm_read_bytes_per_step"] + v["hbm_write_bytes_per_step"] for v in asm)

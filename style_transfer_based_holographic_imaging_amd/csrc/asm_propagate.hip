@@ -486,7 +486,10 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
 // ================================================================================================================
 // Transposed-intermediate kernels (32 <= P <= 1024, S a multiple of 16): T and U are [field][kx][y].
 // ================================================================================================================
-constexpr int kTileRows = 16;              // rows per row-kernel block: 16 x 8 B = one 128-B run per kx
+#ifndef HOLO_ASM_TILE_ROWS
+#define HOLO_ASM_TILE_ROWS 16
+#endif
+constexpr int kTileRows = HOLO_ASM_TILE_ROWS;   // rows per row-kernel block: 16 x 8 B = one 128-B run per kx (8: 64-B runs, smaller blocks)
 constexpr int kTilePitch = kTileRows + 1;  // LDS tile [kx][17]: conflict-free for 16 consecutive kx at a fixed row
 
 template <int P>
@@ -500,17 +503,70 @@ struct RowTCfg {
     static constexpr int bpc(int twn) {                           // blocks per CU that LDS and the 32-wave limit allow
         const int by_lds = (int)((160 * 1024) / lds(twn)), by_waves = 2048 / THREADS;
         const int b = by_lds < by_waves ? by_lds : by_waves;
-        return b < 1 ? 1 : (b > 2 ? 2 : b);
+        return b < 1 ? 1 : (b > 4 ? 4 : b);
     }
     static constexpr int waves_per_simd(int twn) { return (bpc(twn) * THREADS + 255) / 256; }
 };
 
 // K1: pack + pad + row FFT of 16 consecutive rows of one field, written transposed
+// ---- transfer-function tables -----------------------------------------------------------------------------------
+// H depends on (|kx|, |ky|) and on the output field's distance only, and a batch usually shares ONE distance (the entry
+// loop back-propagates every hologram by the style distance): evaluating it per column in the column kernel (float64
+// argument, ~330 instructions per thread) was 39 % of that kernel's VALU work.  Output fields fo < kHSlots get a table slot;
+// fo's slot is uid(fo) = the first g < min(fo, kHSlots) with a bit-identical phase constant, else fo itself (fo >= kHSlots
+// without a match: no table, H is evaluated in the column kernel as before).  Only slots that represent themselves are
+// filled — by EXTRA BLOCKS of the forward row kernel, which is memory-bound and has the VALU to spare, so the table costs
+// no launch and no time on the critical path.  Layout [slot][|kx|][|ky|] (P/2+1 squared, complex64): a column's values are
+// contiguous.  Values are produced by the same transfer_value(): results are bit-identical to the inline evaluation.
+constexpr int kHSlots = 64;
+template <int P>
+__host__ __device__ constexpr size_t htab_elems() { return (size_t)(P / 2 + 1) * (P / 2 + 1); }
+
+// slot of output field fo (or -1), evaluated by the first wave of a block: lanes compare the phase constants of the first
+// kHSlots fields with fo's
+__device__ __forceinline__ int htab_uid_wave(const double* __restrict__ phase_const, int fo, int lane) {
+    static_assert(kHSlots == 64, "one lane per candidate");
+    const double mine = phase_const[fo];
+    const bool eq = lane < fo && phase_const[lane < fo ? lane : 0] == mine;
+    const unsigned long long m = __ballot(eq);
+    return m ? __ffsll((long long)m) - 1 : (fo < kHSlots ? fo : -1);
+}
+
 template <int P, bool PAD>
 __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_entries_fwd<P>())) void asm_rows_fwd_t_kernel(
     const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
-    float phase_scale, v2f* __restrict__ tbuf) {
+    float phase_scale, v2f* __restrict__ tbuf, int tab_blocks, v2f* __restrict__ htab,
+    const double* __restrict__ phase_const, int n_out, double inv_ppx, double lam2, double lamb) {
     using C = RowTCfg<P>;
+    if ((int)blockIdx.x < tab_blocks) {
+        // table blocks (dispatched FIRST, so that they run beside the row blocks instead of forming a tail): block j computes
+        // entries [j*THREADS, (j+1)*THREADS) of EVERY slot that represents itself (usually one).  The constants of the slots
+        // go through LDS once; slot s represents itself unless an earlier slot holds the same bits.  (One block per
+        // (slot, piece) would be 64x more blocks, nearly all exiting at once: +4 us on this kernel, measured.)
+        constexpr int HN = P / 2 + 1;
+        __shared__ double s_pc[kHSlots];
+        __shared__ int s_dup[kHSlots];
+        const int slots = n_out < kHSlots ? n_out : kHSlots;
+        const int tid = threadIdx.x;
+        if (tid < kHSlots) {
+            s_pc[tid] = phase_const[tid < slots ? tid : 0];
+            s_dup[tid] = 0;
+        }
+        __syncthreads();
+        for (int q = tid; q < kHSlots * kHSlots; q += C::THREADS) {
+            const int sl = q / kHSlots, g = q % kHSlots;
+            if (g < sl && sl < slots && s_pc[g] == s_pc[sl]) s_dup[sl] = 1;   // benign race: every writer stores 1
+        }
+        __syncthreads();
+        const int i = (int)blockIdx.x * C::THREADS + tid;
+        if (i >= (int)htab_elems<P>()) return;
+        const int akx = i / HN, aky = i % HN;
+        const double fx = (double)akx * inv_ppx, fy = (double)aky * inv_ppx;
+        const double f2 = fx * fx + fy * fy;
+        for (int slot = 0; slot < slots; ++slot)
+            if (!s_dup[slot]) htab[(size_t)slot * htab_elems<P>() + i] = transfer_value(f2, lam2, s_pc[slot] / lamb);
+        return;
+    }
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
     constexpr int R1 = fft_radix<P, -1>(0);
@@ -523,7 +579,7 @@ __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_
 
     const int tid = threadIdx.x;
     const int seq = tid / G, t = tid % G;
-    const long row0 = (long)blockIdx.x * kTileRows;
+    const long row0 = (long)((int)blockIdx.x - tab_blocks) * kTileRows;
     const long f = row0 / S;
     const int y0 = (int)(row0 % S);
     v2f* my = buf + seq * PITCH;
@@ -600,7 +656,7 @@ struct ColTCfg {
 template <int P, bool PAD>
 __global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) void asm_cols_t_kernel(
     const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const double* __restrict__ phase_const,
-    int n_dist, double inv_ppx, double lam2, double lamb, int ablate) {
+    int n_dist, double inv_ppx, double lam2, double lamb, int ablate, const v2f* __restrict__ htab) {
     using C = ColTCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int CW = C::CW, G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
@@ -612,6 +668,7 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) vo
     v2f* twf = reinterpret_cast<v2f*>(smem_raw);
     v2f* twi = SYM ? twf : twf + tw_entries_fwd<P>();
     v2f* cols = twf + C::TWN;
+    __shared__ int s_uid;
 
     const int tid = threadIdx.x;
     const int fo = blockIdx.y;          // output field = field * n_dist + dist
@@ -621,6 +678,10 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) vo
     v2f* my = cols + col * PITCH;
     fft_fill_twiddles<P, -1>(twf, tid, THREADS);
     if (!SYM) fft_fill_twiddles<P, +1>(twi, tid, THREADS);
+    if (tid < 64) {   // THREADS >= 64 for every P of this path except the smallest, which skips the table
+        const int u = (THREADS >= 64 && htab != nullptr) ? htab_uid_wave(phase_const, fo, tid) : -1;
+        if (tid == 0) s_uid = u;
+    }
 
     // the column's S values are contiguous; rows above/below the field are copies of its first/last row spectrum
     const v2f* src = tbuf + ((long)f * P + kx) * S;
@@ -647,24 +708,35 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) vo
     __syncthreads();  // twiddle tables: the only block barrier
     if (!(ablate & 2)) fft_run<P, G, -1>(v, my, twf, t);   // spectrum in registers at ky = fft_elem_index<P,G,RL>(t,e)
 
-    // transfer function: one value per (column, |ky|), shared through LDS by rows ky and P-ky.  The column's
-    // LDS region is private to its G lanes (one wave or less): wave-local ordering, no block barrier.
-    fft_sync<G>();
-    {
-        // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
-        const double c_over_l = phase_const[fo] / lamb;
-        const double fx = (double)(kx < P / 2 ? kx : kx - P) * inv_ppx;
-        const double fx2 = fx * fx;
-        for (int m = t; m <= P / 2; m += G) {
-            const double fy = (double)m * inv_ppx;
-            my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
-        }
-    }
-    fft_sync<G>();
+    const int uid = s_uid;   // written before the twiddle barrier above
+    if (uid >= 0) {
+        // transfer function from this distance's table: the column's |ky| values are contiguous
+        const v2f* __restrict__ hcol = htab + (size_t)uid * htab_elems<P>() + (size_t)(kx <= P / 2 ? kx : P - kx) * (P / 2 + 1);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int ky = fft_elem_index<P, G, RL>(t, e);
-        v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
+        for (int e = 0; e < E; ++e) {
+            const int ky = fft_elem_index<P, G, RL>(t, e);
+            v[e] = cmul(v[e], hcol[ky <= P / 2 ? ky : P - ky]);
+        }
+    } else {
+        // no table slot (more than kHSlots distinct distances in the call): one value per (column, |ky|), shared through
+        // LDS by rows ky and P-ky.  The column's LDS region is private to its G lanes: wave-local ordering, no block barrier.
+        fft_sync<G>();
+        {
+            // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
+            const double c_over_l = phase_const[fo] / lamb;
+            const double fx = (double)(kx <= P / 2 ? kx : P - kx) * inv_ppx;
+            const double fx2 = fx * fx;
+            for (int m = t; m <= P / 2; m += G) {
+                const double fy = (double)m * inv_ppx;
+                my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
+            }
+        }
+        fft_sync<G>();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int ky = fft_elem_index<P, G, RL>(t, e);
+            v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
+        }
     }
     if (!(ablate & 2)) fft_run<P, G, +1>(v, my, twi, t);
 
@@ -756,6 +828,7 @@ struct AsmArgs {
     float2 *twf, *twi;
     double* f2;
     float2 *tbuf, *ubuf;
+    float2* htab;   // transfer-function tables (transposed-layout path), or nullptr
     hipStream_t stream;
     int ablate;   // -DHOLO_DEBUG builds only (HOLO_ASM_ABLATE): 1 = skip H evaluation, 2 = skip the FFT passes; 0 in the shipped build
 };
@@ -830,11 +903,18 @@ static int launch_asm_t(const AsmArgs& a) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
     }
     const long blocks_in = (long)a.n_fields * S / kTileRows;
-    hipLaunchKernelGGL((asm_rows_fwd_t_kernel<P, PAD>), dim3((unsigned)blocks_in), dim3(R::THREADS), row_lds_f, a.stream,
-                       a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf));
-    hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD>), dim3(P / C::CW, a.n_fields * a.n_dist), dim3(C::THREADS), C::LDS, a.stream,
+    // transfer-function tables: extra blocks of the row kernel (blocks of the smallest grids have fewer than 64 threads: no table)
+    const int n_out = a.n_fields * a.n_dist;
+    const bool tables = R::THREADS >= 64 && C::THREADS >= 64 && a.htab != nullptr;
+    const int slots = n_out < kHSlots ? n_out : kHSlots;
+    const long tab_blocks = tables ? (long)((htab_elems<P>() + R::THREADS - 1) / R::THREADS) : 0;
+    (void)slots;
+    hipLaunchKernelGGL((asm_rows_fwd_t_kernel<P, PAD>), dim3((unsigned)(blocks_in + tab_blocks)), dim3(R::THREADS), row_lds_f,
+                       a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf),
+                       (int)tab_blocks, reinterpret_cast<v2f*>(a.htab), a.phase_const, n_out, 1.0 / a.ppx, a.lam2, a.lamb);
+    hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD>), dim3(P / C::CW, n_out), dim3(C::THREADS), C::LDS, a.stream,
                        reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
-                       1.0 / a.ppx, a.lam2, a.lamb, a.ablate);
+                       1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr);
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
     hipLaunchKernelGGL((asm_rows_inv_t_kernel<P, PAD>), dim3((unsigned)(blocks_in * a.n_dist)), dim3(R::THREADS), row_lds_i,
                        a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0, a.os1, scale);
@@ -992,11 +1072,21 @@ constexpr size_t kTableBytes = 2 * kTwSlots * sizeof(float2) + kTwSlots * sizeof
 
 extern "C" {
 
+// bytes of the transfer-function tables behind the two intermediates (transposed-layout path only)
+static size_t asm_htab_bytes(int n_fields, int n_dist, size_t p) {
+    const bool transposed = (p & (p - 1)) == 0 && p >= 32 && p <= 1024;
+    if (!transposed) return 0;
+    const size_t n_out = (size_t)n_fields * (size_t)n_dist;
+    const size_t slots = n_out < (size_t)holo::kHSlots ? n_out : (size_t)holo::kHSlots;
+    return slots * (p / 2 + 1) * (p / 2 + 1) * sizeof(float2);
+}
+
 size_t holo_asm_workspace_bytes(int n_fields, int n_dist, int s, int zero_padding) {
     if (n_fields <= 0 || n_dist <= 0 || s <= 0) return 0;
     const size_t p = zero_padding ? 2 * (size_t)s : (size_t)s;
     const size_t slab = (size_t)s * p * sizeof(float2);
-    return holo::kTableBytes + slab * (size_t)n_fields + slab * (size_t)n_fields * (size_t)n_dist;
+    return holo::kTableBytes + slab * (size_t)n_fields + slab * (size_t)n_fields * (size_t)n_dist +
+           asm_htab_bytes(n_fields, n_dist, p);
 }
 
 int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_stride, long in1_stride,
@@ -1048,6 +1138,7 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
     a.f2 = reinterpret_cast<double*>(a.twi + kTwSlots);
     a.tbuf = reinterpret_cast<float2*>(static_cast<unsigned char*>(workspace) + kTableBytes);
     a.ubuf = a.tbuf + (size_t)n_fields * s * p;
+    a.htab = asm_htab_bytes(n_fields, n_dist, (size_t)p) ? a.ubuf + (size_t)n_fields * n_dist * s * p : nullptr;
     a.stream = as_stream(stream);
     a.ablate = 0;
 #ifdef HOLO_DEBUG   // timing experiments only (wrong results): never read in the shipped build

@@ -207,3 +207,26 @@ def test_holo_generator_normalisation_constants(dev, pn, dn, dc):
     amp2, ph2 = amp.repeat(1, 2, 1, 1) * torch.tensor([1.0, 0.5]).view(1, 2, 1, 1), ph.repeat(1, 2, 1, 1)
     ref2 = orc.holo_generator(hp, amp2, ph2, d, complex_number=True)          # C = 2: d broadcast over channels
     assert cplx_rel(hgp(amp2.to(dev), ph2.to(dev), d.to(dev), complex_number=True), ref2) < 1e-5
+
+
+def test_transfer_function_tables_dedupe_distances(hg, dev):
+    """Output fields that share a distance share one transfer-function table (64 slots; filled by extra blocks of the
+    forward row kernel); fields beyond the slots evaluate H in the column kernel.  Every field of a mixed batch — equal
+    distances, distinct ones, more than 64 distinct ones — must come out bit-identical to the same field propagated alone."""
+    g = torch.Generator().manual_seed(11)
+    n, s = 90, 32
+    amp = (torch.rand(n, 1, s, s, generator=g) + 0.2).to(dev)
+    ph = (torch.rand(n, 1, s, s, generator=g) * 6 - 3).to(dev)
+    d = torch.empty(n)
+    d[:10] = 0.3                                   # shared slot 0
+    d[10:80] = torch.linspace(-0.9, 0.9, 70)       # 70 distinct: the slots run out at field 64
+    d[80:] = d[70:80]                              # repeats of distances that own no slot: inline evaluation
+    d = d.view(n, 1, 1, 1).to(dev)
+    a_all, p_all = hg(amp, ph, d, return_field=True)
+    for i in (0, 9, 10, 63, 64, 79, 80, 89):
+        a_i, p_i = hg(amp[i:i + 1], ph[i:i + 1], d[i:i + 1], return_field=True)
+        assert torch.equal(a_all[i:i + 1], a_i) and torch.equal(p_all[i:i + 1], p_i), i
+    from hip_helpers import orc
+    ref = orc.holo_generator(orc.HoloParams(), amp.cpu(), ph.cpu(), d.cpu(), complex_number=True)
+    from hip_helpers import cplx_rel
+    assert cplx_rel(torch.polar(a_all, p_all), ref) < 1e-5

@@ -53,7 +53,10 @@ def test_argument_validation_needs_no_gpu():
     assert lib.holo_asm_propagate(fake, None, 0, 1, 1, fake, fake, 0, 1, 1, fake, 1, 1, 64, 1, 5e-7, 1e-6, 1.0,
                                   fake, 1 << 30, None) == 1                                      # missing phase
     assert lib.holo_adain_apply_f32(fake, fake, fake, fake, fake, 0, 1.5, fake, 1, 4, 64, None) == 1  # alpha
-    assert lib.holo_asm_workspace_bytes(2, 3, 64, 1) == 3 * 4096 * 8 + 64 * 128 * 8 * (2 + 6)
+    # tables of the generic path + T (2 fields) + U (6 output fields) + one 65 x 65 transfer-function table per output field
+    assert lib.holo_asm_workspace_bytes(2, 3, 64, 1) == 3 * 4096 * 8 + 64 * 128 * 8 * (2 + 6) + 6 * 65 * 65 * 8
+    assert lib.holo_asm_workspace_bytes(200, 1, 64, 1) == 3 * 4096 * 8 + 64 * 128 * 8 * 400 + 64 * 65 * 65 * 8   # at most 64 table slots
+    assert lib.holo_asm_workspace_bytes(1, 1, 1024, 1) == 3 * 4096 * 8 + 1024 * 2048 * 8 * 2                     # P = 2048: row-major path, no table
     assert lib.holo_conv3x3_packed_elems(128, 64) == 9 * 64 * 128
     assert lib.holo_unwrap2d_workspace_bytes(3, 10, 20) == 3 * 200 * 24
     assert lib.holo_unwrap2d_f32(fake, 100, fake, 100, 1, 10, 10, None, 0, None) == 1             # no workspace

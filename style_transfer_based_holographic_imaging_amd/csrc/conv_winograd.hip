@@ -24,7 +24,7 @@
 // Two barriers per chunk; the DMA of the next chunk's halo / weights is spread over the first MFMA gaps of a step.
 //
 // Epilogue: A^T M A per lane (the 16 positions of one (tile, channel) sit in the same register of the 16
-// accumulators), bias, ReLU, optional 2x2 max-pool (= exactly one Winograd tile), NHWC stores of 128-B runs.
+// accumulators), bias, ReLU, optional 2x2 max-pool (= exactly one Winograd tile), NHWC stores of 16 bytes per lane.
 #include "common.h"
 
 #ifndef WINO_ABL
@@ -233,14 +233,14 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
             // behind its first and its third MFMA, never back to back (two in front of the slice's MFMAs left ~140 cycles
             // per slice uncovered: 17 % of a step).
             static_assert(kCW == 4, "DMA placement below assumes four MFMAs per position");
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][0], bv[0], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[0], V[p][0], acc[p], 0, 0, 0);
             if (dma == 1 && 2 * p < kARounds) { WINO_LOAD_A_ROUND(gsrc, nbuf, 2 * p, off0) }
             if (dma == 2 && 2 * p < kBRounds) { WINO_LOAD_B_ROUND(gsrc, nbuf, 2 * p) }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][1], bv[1], acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][2], bv[2], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[1], V[p][1], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[2], V[p][2], acc[p], 0, 0, 0);
             if (dma == 1 && 2 * p + 1 < kARounds) { WINO_LOAD_A_ROUND(gsrc, nbuf, 2 * p + 1, off1) }
             if (dma == 2 && 2 * p + 1 < kBRounds) { WINO_LOAD_B_ROUND(gsrc, nbuf, 2 * p + 1) }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p][3], bv[3], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[3], V[p][3], acc[p], 0, 0, 0);
             if (2 * p + 2 < kARounds) off0 = plan[(2 * p + 2) * kThreads];
             if (2 * p + 3 < kARounds) off1 = plan[(2 * p + 3) * kThreads];
             if constexpr (do_t) {
@@ -270,15 +270,14 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     };
 
     // ---- epilogue of one tile: Y = A^T M A, bias, ReLU, optional pool, NHWC store ----------------------------------
-    // lane: channel n0 + li; register r: tile m = (r&3) + 8*(r>>2) + 4*hsel of the wave's 32 (tile row m>>3, column m&7)
+    // lane: tile li of the wave's 32 (tile row li>>3, column li&7); register r: channel (r&3) + 8*(r>>2) + 4*hsel of the block's 32
     auto epilogue = [&](const Tile& tl) {
         // lane coordinates made opaque: nothing of the epilogue's addressing may be hoisted out of the persistent loop (hoisted
         // values are live across the MFMA loop, where every VGPR is taken, and come back as scratch reloads in front of the
         // LDS-DMAs: s_waitcnt vmcnt(0) then serialises the staging pipeline)
         int li = li_, hsel = hsel_, wave = wave_;
         asm volatile("" : "+v"(li), "+v"(hsel), "+v"(wave));
-        const int co = tl.nb * kTN + li;
-        const float bv = bias[co];
+        const int co0 = tl.nb * kTN + 4 * hsel;      // first channel of this lane's quad 0 (quad q: + 8q)
         const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
         float* __restrict__ yimg = y + (size_t)tl.img * (pool ? (size_t)Ho * Wo : (size_t)H * W) * Cout;
         const bool full = tl.y0 + kPH <= H && tl.x0 + kPW <= W;
@@ -332,43 +331,44 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
                 o11 -= u1;
             }
         }
+        // The product is computed TRANSPOSED (weights as the A operand): lane = tile li, register r = channel
+        // (r&3) + 8*(r>>2) + 4*hsel of the block's 32, so a quad of registers is 4 consecutive channels = one 16-byte piece of an
+        // NHWC pixel: 16 global_store_dwordx4 per lane instead of 64 global_store_dword (the epilogue is store-issue bound).
+        const int Y = tl.y0 + 2 * (4 * wave + (li >> 3)), X = tl.x0 + 2 * (li & 7);
+        const bool in00 = Y < H && X < W, in01 = Y < H && X + 1 < W, in10 = Y + 1 < H && X < W, in11 = Y + 1 < H && X + 1 < W;
+        float* __restrict__ q00 = yimg + ((size_t)Y * W + X) * Cout + co0;
+        float* __restrict__ qp = yimg + ((size_t)(Y >> 1) * Wo + (X >> 1)) * Cout + co0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;
-            const int Y = tl.y0 + 2 * (4 * wave + (m >> 3)), X = tl.x0 + 2 * (m & 7);
-            float o[2][2] = {{o00[r] + bv, o01[r] + bv}, {o10[r] + bv, o11[r] + bv}};
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + co0 + 8 * q);
+            float4 o[2][2];
+            o[0][0] = make_float4(o00[4 * q] + b4.x, o00[4 * q + 1] + b4.y, o00[4 * q + 2] + b4.z, o00[4 * q + 3] + b4.w);
+            o[0][1] = make_float4(o01[4 * q] + b4.x, o01[4 * q + 1] + b4.y, o01[4 * q + 2] + b4.z, o01[4 * q + 3] + b4.w);
+            o[1][0] = make_float4(o10[4 * q] + b4.x, o10[4 * q + 1] + b4.y, o10[4 * q + 2] + b4.z, o10[4 * q + 3] + b4.w);
+            o[1][1] = make_float4(o11[4 * q] + b4.x, o11[4 * q + 1] + b4.y, o11[4 * q + 2] + b4.z, o11[4 * q + 3] + b4.w);
             if (relu) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    o[a][0] = fmaxf(o[a][0], 0.0f);
-                    o[a][1] = fmaxf(o[a][1], 0.0f);
-                }
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        o[a][b] = make_float4(fmaxf(o[a][b].x, 0.0f), fmaxf(o[a][b].y, 0.0f), fmaxf(o[a][b].z, 0.0f), fmaxf(o[a][b].w, 0.0f));
             }
             if (!pool) {
-                if (full) {   // the block's 32 x 16 pixels lie inside the image: no per-store bounds test (block-uniform)
-                    float* __restrict__ q = yimg + ((size_t)Y * W + X) * Cout + co;
-                    q[0] = o[0][0];
-                    q[Cout] = o[0][1];
-                    q[(size_t)W * Cout] = o[1][0];
-                    q[(size_t)W * Cout + Cout] = o[1][1];
-                } else {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            if (Y + a < H && X + b < W) yimg[((size_t)(Y + a) * W + (X + b)) * Cout + co] = o[a][b];
-                }
-            } else if (full) {
-                yimg[((size_t)(Y >> 1) * Wo + (X >> 1)) * Cout + co] = fmaxf(fmaxf(o[0][0], o[0][1]), fmaxf(o[1][0], o[1][1]));
-            } else if (Y < H && X < W) {
-                // MaxPool2d(2,2,ceil_mode=True): the window is this tile; members beyond the image edge are left out
-                float mx = o[0][0];
-                if (X + 1 < W) mx = fmaxf(mx, o[0][1]);
-                if (Y + 1 < H) {
-                    mx = fmaxf(mx, o[1][0]);
-                    if (X + 1 < W) mx = fmaxf(mx, o[1][1]);
-                }
-                yimg[((size_t)(Y >> 1) * Wo + (X >> 1)) * Cout + co] = mx;
+                float* __restrict__ d = q00 + 8 * q;
+                if (full || in00) *reinterpret_cast<float4*>(d) = o[0][0];
+                if (full || in01) *reinterpret_cast<float4*>(d + Cout) = o[0][1];
+                if (full || in10) *reinterpret_cast<float4*>(d + (size_t)W * Cout) = o[1][0];
+                if (full || in11) *reinterpret_cast<float4*>(d + (size_t)W * Cout + Cout) = o[1][1];
+            } else if (full || in00) {
+                // MaxPool2d(2,2,ceil_mode=True): the window is this tile; members beyond the image edge are left out (post-ReLU
+                // values are >= 0, so an absent member is a 0)
+                auto mx4 = [](float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); };
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 m = o[0][0];
+                m = mx4(m, (full || in01) ? o[0][1] : z);
+                m = mx4(m, (full || in10) ? o[1][0] : z);
+                m = mx4(m, (full || in11) ? o[1][1] : z);
+                *reinterpret_cast<float4*>(qp + 8 * q) = m;
             }
         }
     };

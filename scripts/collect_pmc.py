@@ -31,8 +31,10 @@ ASM = ("asm_rows_fwd", "asm_cols", "asm_rows_inv")
 
 
 def one_pass(counter, outdir, bench_args):
+    """one rocprofv3 pass; `counter` may be a space-separated list (one --pmc group).  Returns rows
+    (dispatch id, kernel name, counter name, value, start ns, end ns) sorted by dispatch."""
     os.makedirs(outdir, exist_ok=True)
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", outdir, "-o", "pmc", "--output-format", "csv", "--",
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counter.split() + ["-d", outdir, "-o", "pmc", "--output-format", "csv", "--",
            sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-events"] + bench_args
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -44,14 +46,20 @@ def one_pass(counter, outdir, bench_args):
     rows = []
     with open(sorted(files)[-1]) as f:
         for row in csv.DictReader(f):
-            if row["Counter_Name"] == counter:
-                rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"])))
+            if row["Counter_Name"] in counter.split():
+                rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], row["Counter_Name"], float(row["Counter_Value"]),
+                             int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
     rows.sort()
     return rows
 
 
 def last_step(rows):
     """dispatches of the last bench step: from the last conv_first launch on (each step starts with it)"""
+    firsts = sorted({r[0] for r in rows if "conv_first_kernel" in r[1]})
+    if len(firsts) > 2:
+        lo = firsts[2]
+        hi = firsts[3] if len(firsts) > 3 else 1 << 60
+        return [r for r in rows if lo <= r[0] < hi]
     starts = [i for i, r in enumerate(rows) if "conv_first_kernel" in r[1]]
     # bench: 1 warm-up + 2 timed steps + (unwrap probe step, f32s steps) afterwards; take the 3rd start (2nd timed step)
     i0 = starts[2] if len(starts) > 2 else starts[-1]
@@ -70,7 +78,7 @@ def main():
     res = {}
     for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
         rows = last_step(one_pass(counter, os.path.join(args.scratch, counter.lower()), args.bench_args))
-        for _, name, val in rows:
+        for _, name, _cn, val, _t0, _t1 in rows:
             short = name.split("(")[0]
             key = next((k for pre, k in KEYS if pre in short), None)
             if key is None:
@@ -88,6 +96,33 @@ def main():
         if key in out["kernels"]:
             c = out["kernels"][key]
             out[field] = (c["hbm_read_bytes_per_step"] + c["hbm_write_bytes_per_step"]) / c["launches_per_step"]
+    # SQ / GRBM view of the dominant kernels (one pass: 8 SQ slots + GRBM): matrix-pipe utilisation, clock, wait fractions.
+    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the chip's 1024 SIMDs; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count
+    # quad-cycles per wave; GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, cycle constants / DVFS notes).
+    sq = "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+    try:
+        rows = last_step(one_pass(sq, os.path.join(args.scratch, "sq"), args.bench_args))
+        agg = {}
+        for did, name, cn, val, t0, t1 in rows:
+            short = name.split("(")[0]
+            key = next((k for pre, k in KEYS if pre in short), None)
+            if key not in ("wino", "conv"):
+                continue
+            a = agg.setdefault(key, {"ns": {}, "c": {}})
+            a["ns"][did] = t1 - t0
+            a["c"][cn] = a["c"].get(cn, 0.0) + val
+        for key, a in agg.items():
+            c, ns = a["c"], sum(a["ns"].values())
+            cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            out["kernels"].setdefault(key, {})["sq"] = {
+                "launches": len(a["ns"]), "ns_profiled": ns, "clock_mhz": round(cyc / ns * 1e3, 1) if ns else None,
+                "mfma_pipe_util": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024.0), 4) if cyc else None,
+                "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
+                "wait_inst_any_frac": round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
+                "active_inst_any_frac": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
+                "raw": c}
+    except SystemExit as e:   # the traffic numbers stand on their own
+        out["sq_error"] = str(e)[:300]
     asm = [v for k, v in out["kernels"].items() if k in ASM]
     if asm:
         out["asm_hbm_bytes_per_call"] = sum(v["hbm_read_bytes_per_step"] + v["hbm_write_bytes_per_step"] for v in asm)

@@ -9,8 +9,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "oracle"))
-from holo_oracle import HoloParams  # noqa: E402
+from bench import HoloParams  # noqa: E402  (the five optics attributes Holo_Generator reads)
 from utils.Forward_model import Holo_Generator  # noqa: E402
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase-unwrapping micro-benchmark: `python scripts/bench_unwrap.py [B] [S] [iters] [kind]`, kind = smooth | noisy |
+"""Phase-unwrapping micro-benchmark: `python tests/diagnostics/bench_unwrap.py [B] [S] [iters] [kind]`, kind = smooth | noisy |
 focus (the back-propagated phase of a synthetic network step).  Prints ms per batch and images/s; with the oracle
 importable also times the sequential restatement on one image for scale."""
 import os
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 sys.path.insert(0, os.path.join(REPO, "oracle"))

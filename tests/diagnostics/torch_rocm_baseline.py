@@ -4,7 +4,7 @@ hipFFT): the same step as bench.py (field_retrieval + back-propagation, pre-unwr
 Diagnostic only (test infrastructure: it drives the oracle's functional restatement on the device); the
 number is quoted in DESIGN.md next to the HIP path's.
 
-  python scripts/torch_rocm_baseline.py [--batch 64] [--size 256] [--steps 10]
+  python tests/diagnostics/torch_rocm_baseline.py [--batch 64] [--size 256] [--steps 10]
 """
 import argparse
 import json
@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "oracle"))
 import holo_oracle as orc  # noqa: E402

@@ -10,6 +10,7 @@ exposes one as the reference's logical ``(B,C,H,W)`` shape without a copy (chann
 from __future__ import annotations
 
 import math
+import threading
 
 import torch
 
@@ -20,15 +21,18 @@ from ._lib import check, lib
 # device of the launch being prepared: set by _req from the tensors of the call, read by _stream / _launch.  A launch
 # goes to the current stream OF THE TENSORS' DEVICE and is issued with that device current (the C-ABI launches on
 # whatever device is current, and hipFuncSetAttribute is per device), whatever torch.cuda.current_device() says.
-_DEV = None
+class _Launch(threading.local):      # per Python thread: two threads driving two GPUs must not see each other's device
+    dev = None
+
+
+_LAUNCH = _Launch()
 
 
 def _stream():
-    return torch.cuda.current_stream(_DEV).cuda_stream
+    return torch.cuda.current_stream(_LAUNCH.dev).cuda_stream
 
 
 def _req(*tensors):
-    global _DEV
     dev = None
     for t in tensors:
         if not isinstance(t, torch.Tensor) or not t.is_cuda:
@@ -39,7 +43,7 @@ def _req(*tensors):
             dev = t.device
         elif t.device != dev:
             raise RuntimeError(f"holo HIP ops need all tensors of a call on one device; got {dev} and {t.device}")
-    _DEV = dev
+    _LAUNCH.dev = dev
 
 
 def set_conv_tile(tile: int):
@@ -152,8 +156,9 @@ _TIMER = None
 def _launch(name, fn, flops=0.0, nbytes=0.0, fresh=False):
     """fresh=True: start this launch's clock right before it (used where torch's own small element-wise launches
     precede ours and must not be charged to the kernel's roofline figure)."""
-    if _DEV is not None and _DEV.index != torch.cuda.current_device():
-        with torch.cuda.device(_DEV):      # e.g. --device cuda:1 without torch.cuda.set_device
+    dev = _LAUNCH.dev
+    if dev is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):      # e.g. --device cuda:1 without torch.cuda.set_device
             return _launch(name, fn, flops, nbytes, fresh)
     if _TIMER is None:
         check(fn(), name)

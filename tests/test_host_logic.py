@@ -216,7 +216,7 @@ def test_ops_reject_tensors_on_different_devices_and_follow_the_tensors_device()
         t.is_cuda, t.device = True, torch.device("cuda", idx)
         return t
     ops._req(fake(1), fake(1))
-    assert ops._DEV == torch.device("cuda", 1)
+    assert ops._LAUNCH.dev == torch.device("cuda", 1)
     with pytest.raises(RuntimeError, match="one device"):
         ops._req(fake(0), fake(1))
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -100,9 +100,10 @@ class Plan:
         self.conv_algo = conv_algo  # fp32 3x3 layers: "direct" (implicit GEMM), "winograd" (F(2x2,3x3)), "auto" (by size)
         self._packed = {}
 
-    # Winograd blocks are 32 x 16 pixels x 32 channels, one per CU: below ~2 blocks per CU (the bundled 5 x 128x128
-    # batches) the direct kernel's smaller tiles fill the chip better
-    WINO_MIN_BLOCKS = 512
+    # Winograd blocks are 32 x 16 pixels x 32 channels, one per CU (256 of them): measured over batch 1..64 at 128^2 and 256^2
+    # (scripts/algo_sweep.sh) it wins from about half a wave of blocks up; below that the direct kernel's smaller tiles
+    # fill the chip better
+    WINO_MIN_BLOCKS = 128
 
     def _use_winograd(self, step, x):
         if self.dtype != torch.float32 or step.kind != "conv" or self.conv_algo == "direct" or step.conv.in_channels < 32:

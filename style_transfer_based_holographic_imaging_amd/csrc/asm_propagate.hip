@@ -486,6 +486,9 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
 // ================================================================================================================
 // Transposed-intermediate kernels (32 <= P <= 1024, S a multiple of 16): T and U are [field][kx][y].
 // ================================================================================================================
+#ifndef HOLO_ASM_PERSIST_ROWS
+#define HOLO_ASM_PERSIST_ROWS 1   // inverse row kernel of the transposed path at P >= 1024: persistent blocks that prefetch the next tile
+#endif
 #ifndef HOLO_ASM_TILE_ROWS
 #define HOLO_ASM_TILE_ROWS 16
 #endif
@@ -755,61 +758,79 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) vo
 template <int P, bool PAD>
 __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_entries_inv<P>())) void asm_rows_inv_t_kernel(
     const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode,
-    long ostride0, long ostride1, float scale) {
+    long ostride0, long ostride1, float scale, int n_tiles) {
     using C = RowTCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
     constexpr int R1 = fft_radix<P, +1>(0);
     constexpr int RL = fft_radix<P, +1>(FftPlan<P>::n - 1);
     constexpr int TWN = tw_entries_inv<P>();
+    constexpr int LD = P * (kTileRows / 2) / THREADS;   // 16-byte pieces of a tile per thread (= E/2)
+    static_assert(LD * THREADS == P * (kTileRows / 2), "the tile divides evenly over the block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* tw = reinterpret_cast<v2f*>(smem_raw);
     v2f* buf = tw + TWN;
 
     const int tid = threadIdx.x;
     const int seq = tid / G, t = tid % G;
-    const long row0 = (long)blockIdx.x * kTileRows;
-    const long fo = row0 / S;
-    const int y0 = (int)(row0 % S);
     v2f* my = buf + seq * PITCH;
     fft_fill_twiddles<P, +1>(tw, tid, THREADS);
-    // U^T[fo][kx][y0 .. y0+15] -> tile[kx][row]
-    {
-        const v2f* src = ubuf + ((long)fo * P) * S + y0;
-        for (int q = tid; q < P * (kTileRows / 2); q += THREADS) {
-            const int kx = q / (kTileRows / 2), j = q % (kTileRows / 2);
-            const float4 d = *reinterpret_cast<const float4*>(src + (long)kx * S + 2 * j);
-            buf[kx * kTilePitch + 2 * j] = v2f{d.x, d.y};
-            buf[kx * kTilePitch + 2 * j + 1] = v2f{d.z, d.w};
+    // The grid may be persistent (P >= 1024: one block per CU): the NEXT tile's 16-byte pieces are then requested into
+    // registers before the current tile's transform and epilogue, so the memory pipe stays busy across the block's
+    // barrier-separated phases.  With one tile per block (P <= 512) the loop runs once.
+    auto load_tile = [&](int tile, float4 (&pre)[LD]) {
+        const long row0 = (long)tile * kTileRows;
+        const v2f* src = ubuf + (row0 / S) * P * S + (row0 % S);
+#pragma unroll
+        for (int l = 0; l < LD; ++l) {
+            const int q = tid + l * THREADS;
+            pre[l] = *reinterpret_cast<const float4*>(src + (long)(q / (kTileRows / 2)) * S + 2 * (q % (kTileRows / 2)));
         }
-    }
-    __syncthreads();
-    v2f v[E];
+    };
+    float4 pre[LD];
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile, pre);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        // U^T[fo][kx][y0 .. y0+15] -> tile[kx][row]
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = buf[fft_elem_index<P, G, R1>(t, e) * kTilePitch + seq];
-    __syncthreads();  // the tile is consumed: its space becomes the rows' FFT buffers
-    fft_run<P, G, +1>(v, my, tw, t);
-    {
-        const int y = y0 + seq;
+        for (int l = 0; l < LD; ++l) {
+            const int q = tid + l * THREADS;
+            const int kx = q / (kTileRows / 2), j = q % (kTileRows / 2);
+            buf[kx * kTilePitch + 2 * j] = v2f{pre[l].x, pre[l].y};
+            buf[kx * kTilePitch + 2 * j + 1] = v2f{pre[l].z, pre[l].w};
+        }
+        __syncthreads();   // (also covers the twiddle table on the first tile)
+        v2f v[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int r = e % RL;
-            // centre crop (Angular_Spectrum_Method.py:34): with padding only the middle r-slices survive
-            if (PAD && ((r + 1) * 4 <= RL || r * 4 >= 3 * RL)) continue;
-            const int i = fft_elem_index<P, G, RL>(t, e);
-            const int x = PAD ? i - S / 2 : i;
-            const v2f o = v[e] * scale;
-            const long pix = (long)y * S + x;
-            if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
-                out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
-                out1[fo * ostride1 + pix] = atan2_poly(o.y, o.x);
-            } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
-                const float a = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
-                out0[fo * ostride0 + pix] = a * a;
-            } else {
-                reinterpret_cast<v2f*>(out0)[fo * ostride0 + pix] = o;
+        for (int e = 0; e < E; ++e) v[e] = buf[fft_elem_index<P, G, R1>(t, e) * kTilePitch + seq];
+        __syncthreads();  // the tile is consumed: its space becomes the rows' FFT buffers
+        if (tile + (int)gridDim.x < n_tiles) load_tile(tile + gridDim.x, pre);
+        fft_run<P, G, +1>(v, my, tw, t);
+        {
+            const long row0 = (long)tile * kTileRows;
+            const long fo = row0 / S;
+            const int y = (int)(row0 % S) + seq;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int r = e % RL;
+                // centre crop (Angular_Spectrum_Method.py:34): with padding only the middle r-slices survive
+                if (PAD && ((r + 1) * 4 <= RL || r * 4 >= 3 * RL)) continue;
+                const int i = fft_elem_index<P, G, RL>(t, e);
+                const int x = PAD ? i - S / 2 : i;
+                const v2f o = v[e] * scale;
+                const long pix = (long)y * S + x;
+                if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
+                    out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
+                    out1[fo * ostride1 + pix] = atan2_poly(o.y, o.x);
+                } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
+                    const float a = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
+                    out0[fo * ostride0 + pix] = a * a;
+                } else {
+                    reinterpret_cast<v2f*>(out0)[fo * ostride0 + pix] = o;
+                }
             }
         }
+        __syncthreads();   // every row is done with its FFT buffer before the next tile is written over them
     }
 }
 
@@ -916,8 +937,13 @@ static int launch_asm_t(const AsmArgs& a) {
                        reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
                        1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr);
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
-    hipLaunchKernelGGL((asm_rows_inv_t_kernel<P, PAD>), dim3((unsigned)(blocks_in * a.n_dist)), dim3(R::THREADS), row_lds_i,
-                       a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0, a.os1, scale);
+    const long tiles_out = blocks_in * a.n_dist;
+    const long inv_slots = (long)device_cus() * R::bpc(tw_entries_inv<P>());
+    // measured (64 fields): P = 1024: 35.5 -> 30.4 us with the persistent grid, P = 512: 23.0 -> 24.3 (one tile per block there)
+    const long inv_grid = (HOLO_ASM_PERSIST_ROWS && P >= 1024 && tiles_out > inv_slots) ? inv_slots : tiles_out;
+    hipLaunchKernelGGL((asm_rows_inv_t_kernel<P, PAD>), dim3((unsigned)inv_grid), dim3(R::THREADS), row_lds_i,
+                       a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0, a.os1, scale,
+                       (int)tiles_out);
     return check_launch("holo_asm_propagate");
 }
 

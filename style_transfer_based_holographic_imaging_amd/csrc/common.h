@@ -39,6 +39,19 @@ inline bool first_call_on_device(unsigned long long& mask) {
     return true;
 }
 
+// compute units of the current device (cached per device; 256 on MI355X): sizes persistent grids
+inline int device_cus() {
+    static int n_cu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+    if (n_cu[dev] <= 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        n_cu[dev] = cus;
+    }
+    return n_cu[dev];
+}
+
 // tile selection of the 3x3 / transposed convolutions: 0 = automatic (shipped), 1..3 force a variant (holo_debug_set_conv_tile,
 // used by the tests that hold the variants bit-identical)
 int conv_tile_override();

@@ -290,6 +290,10 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
         // accumulator tile to the VGPR class for its entire live range, and the register allocator then shuffles tiles between
         // the two files inside the MFMA loop.  The last MFMAs of the tile were issued before the step's closing barrier; the
         // s_nops cover the 16-pass MFMA -> AGPR read hazard, which hipcc does not pad for an asm statement.
+        // the bias quads are requested first: their latency hides behind the accumulator reads and the transform
+        float4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + co0 + 8 * q);
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
         auto rd_tile = [&](const floatx16& t) {
             floatx16 v;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
         float* __restrict__ qp = yimg + ((size_t)(Y >> 1) * Wo + (X >> 1)) * Cout + co0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b4 = *reinterpret_cast<const float4*>(bias + co0 + 8 * q);
+            const float4 b4 = bq[q];
             float4 o[2][2];
             o[0][0] = make_float4(o00[4 * q] + b4.x, o00[4 * q + 1] + b4.y, o00[4 * q + 2] + b4.z, o00[4 * q + 3] + b4.w);
             o[0][1] = make_float4(o01[4 * q] + b4.x, o01[4 * q + 1] + b4.y, o01[4 * q + 2] + b4.z, o01[4 * q + 3] + b4.w);

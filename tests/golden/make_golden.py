@@ -35,20 +35,30 @@ warnings.filterwarnings("ignore")
 
 
 def import_reference():
+    """Import the reference's modules from where they lie.  The repo has same-named drop-in modules (``net``, ``function``
+    and a regular ``utils`` package, which would beat the reference's namespace package wherever it sits on ``sys.path``), so
+    ``utils`` is bound to the reference's directory explicitly and EVERY imported module is checked to come from there."""
     stub = types.ModuleType("skimage")
     stub.restoration = types.ModuleType("skimage.restoration")
     stub.restoration.unwrap_phase = None
     sys.modules["skimage"] = stub
     sys.modules["skimage.restoration"] = stub.restoration
-    sys.path.insert(0, REF)          # reference's net/function/utils win over the repo's
-    sys.path.append(REPO)            # for the synth module only
+    for name in [m for m in sys.modules if m in ("net", "function", "utils") or m.startswith("utils.")]:
+        del sys.modules[name]        # e.g. the repo's own modules imported earlier in this process
+    ref_utils = types.ModuleType("utils")
+    ref_utils.__path__ = [os.path.join(REF, "utils")]
+    sys.modules["utils"] = ref_utils
+    sys.path.insert(0, REF)          # reference's net / function win over the repo's
+    if REPO not in sys.path:
+        sys.path.append(REPO)        # for the synth module only
     import net as ref_net
     import function as ref_function
-    from utils.Forward_model import Holo_Generator
-    from utils.Angular_Spectrum_Method import ASM
-    from utils.functions import field_retrieval
-    assert ref_net.__file__.startswith(REF), ref_net.__file__
-    return ref_net, ref_function, Holo_Generator, ASM, field_retrieval
+    import utils.Forward_model as ref_fm
+    import utils.Angular_Spectrum_Method as ref_asm
+    import utils.functions as ref_fn
+    for mod in (ref_net, ref_function, ref_fm, ref_asm, ref_fn):
+        assert os.path.realpath(mod.__file__).startswith(REF + os.sep), f"{mod.__name__} came from {mod.__file__}, not the reference"
+    return ref_net, ref_function, ref_fm.Holo_Generator, ref_asm.ASM, ref_fn.field_retrieval
 
 
 def build_network(ref_net, seed):

@@ -156,3 +156,37 @@ def test_network_bf16_matches_bf16_emulation(mnist_style):
     assert float((d16.cpu() - ed).abs().max()) < 5e-2
     # against fp32: bf16-sized, not kernel-sized, differences
     assert l2(a16, a32) < 0.12 and l2(p16, p32) < 0.12
+
+
+def test_network_bf16_at_config3_size(mnist_style):
+    """BASELINE configs[2] shape: one 512x512 hologram through the bf16 conv path (the kernels' large-image tiling: 64 x 64
+    ... 512 x 512 feature maps, every pooled / transposed layer), against the CPU bf16-rounding emulation and the fp32 path,
+    then back-propagated by the fp32 propagator (P = 1024) against the oracle's propagator on the same amplitude / phase."""
+    from hip_helpers import DEV, bf16_emulated_field_retrieval, build_network, cplx_rel, holo_generator, orc
+    from style_transfer_based_holographic_imaging_amd import synth
+    network, sds = build_network(0)
+    hg = holo_generator()
+    ph = synth.synthetic_phase_objects(1, 512, seed=1235)          # config 3's generator and seed (SURVEY.md 8d)
+    d_c = synth.synthetic_distances(1, seed=1235)
+    d_s = torch.full((1, 1, 1, 1), 0.2)
+    sv = mnist_style.to(DEV)
+    with torch.no_grad():
+        content = torch.sqrt(hg(torch.full_like(ph, 0.6).to(DEV), ph.to(DEV), d_c.to(DEV)))
+        a32, p32, d32 = network.field_retrieval(content, sv, 1.0, True)
+        network.set_compute_dtype(torch.bfloat16)
+        a16, p16, d16 = network.field_retrieval(content, sv, 1.0, True)
+        a16b, p16b, d16b = network.field_retrieval(content.repeat(2, 1, 1, 1), sv, 1.0, True)
+        fld = hg(a16, p16 * 1.0, -d_s.to(DEV), complex_number=True)
+        network.set_compute_dtype(torch.float32)
+        ea, ep, ed = bf16_emulated_field_retrieval(content.cpu(), mnist_style, sds)
+        same_in = orc.holo_generator(orc.HoloParams(), a16.cpu(), p16.cpu(), -d_s, complex_number=True)
+    assert a16.shape == (1, 1, 512, 512) and a16.dtype == torch.float32
+    assert torch.isfinite(a16).all() and torch.isfinite(p16).all()
+    assert torch.equal(a16b[:1], a16) and torch.equal(a16b[1:], a16) and torch.equal(p16b[1:], p16) and torch.equal(d16b[1:], d16)
+
+    def l2(a, b):
+        return float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
+    assert l2(a16, ea) < 0.1 and l2(p16, ep) < 0.1, (l2(a16, ea), l2(p16, ep))
+    assert float((d16.cpu() - ed).abs().max()) < 5e-2
+    assert l2(a16, a32) < 0.12 and l2(p16, p32) < 0.12
+    assert cplx_rel(fld, same_in) < 1e-5

@@ -177,6 +177,31 @@ def test_256_against_oracle(env, mnist_style):
     assert cplx_rel(fld, f64) < 4.0 * cplx_rel(o[5], f64) + 1e-6
 
 
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_256_bench_kernel_selection_against_oracle(env, mnist_style, algo):
+    """BASELINE configs[1] numerics with the kernel selection PINNED: at 256x256 the headline bench runs every large 3x3
+    layer on the Winograd kernel, and per-algorithm results are bit-exact across batch sizes (test_full_size_properties),
+    so two holograms under set_conv_algo("winograd") are the benchmarked arithmetic.  The 1e-4 bar on amplitude, phase and
+    distance, against the CPU oracle; "direct" is held to the same bar."""
+    from hip_helpers import orc
+    from style_transfer_based_holographic_imaging_amd import synth
+    from utils.functions import field_retrieval
+    dev, hg, network = env["dev"], env["hg"], env["net"]
+    ph = synth.synthetic_phase_objects(2, 256, seed=1234)       # config 2's generator and seed (SURVEY.md 8d)
+    d_c = synth.synthetic_distances(2, seed=1234)
+    with torch.no_grad():
+        content = torch.sqrt(hg(torch.full_like(ph, 0.6).to(dev), ph.to(dev), d_c.to(dev))).cpu()
+        o = orc.net_field_retrieval(content, mnist_style, *env["sds"], 1.0, True)
+        try:
+            network.set_conv_algo(algo)
+            got = field_retrieval(network, content.to(dev), mnist_style.to(dev), 1.0, True)
+        finally:
+            network.set_conv_algo("auto")
+    for i, name in enumerate(("amplitude", "phase", "distance")):
+        e = rel_err(got[i].cpu().reshape(-1), o[i].reshape(-1))
+        assert e < TOL, f"{algo} {name}: {e:.2e}"
+
+
 @pytest.mark.parametrize("size", [512, 1024])
 def test_large_sizes_sit_at_the_fp32_noise_floor(env, mnist_style, size):
     """BASELINE configs 3 / 5 sizes, one hologram each.  The max-norm distance between two fp32 evaluations of this network

@@ -116,6 +116,60 @@ def test_sweep_matches_repeat_idiom(hg, dev):
         assert torch.equal(a_s[:, k:k + 1], a_k) and torch.equal(p_s[:, k:k + 1], p_k)
 
 
+@pytest.mark.parametrize("s,b", [(128, 3), (256, 2), (512, 2), (1024, 1)])
+def test_sweep_at_baseline_sizes(hg, dev, s, b):
+    """BASELINE configs[4] idiom at its own size (and the sizes below it): every field to 8 distances in one sweep.  Covers
+    the n_dist > 1 indexing of every column / inverse-row kernel variant (P = 256, 512: one wave per column; P = 1024: the
+    persistent column kernel; P = 2048: the row-major path).  Held (i) bit-exact against the reference idiom
+    ``forward(a.repeat(n), p.repeat(n), distances)`` (utils/Data_loader.py:59-62) run field by field, and (ii) within 1e-5 of the
+    complex128 oracle, through the complex field so that no angle discontinuity enters."""
+    from hip_helpers import cplx_rel, orc
+    from style_transfer_based_holographic_imaging_amd import synth
+    ph = synth.synthetic_phase_objects(b, s, seed=1237) * 3.0
+    amp = torch.full_like(ph, 0.6) + 0.05 * torch.rand(ph.shape, generator=torch.Generator().manual_seed(s))
+    dist = torch.linspace(-0.1, -0.8, 8)
+    a_s, p_s = hg.sweep(amp.to(dev), ph.to(dev), dist)
+    i_s = hg.sweep(amp.to(dev), ph.to(dev), dist, return_field=False)
+    assert a_s.shape == (b, 8, s, s) and p_s.shape == (b, 8, s, s) and i_s.shape == (b, 8, s, s)
+    hp = orc.HoloParams()
+    for f in range(b):
+        a_k, p_k = hg(amp[f:f + 1].repeat(8, 1, 1, 1).to(dev), ph[f:f + 1].repeat(8, 1, 1, 1).to(dev),
+                      dist.view(8, 1, 1, 1).to(dev), return_field=True)
+        assert torch.equal(a_s[f], a_k[:, 0]) and torch.equal(p_s[f], p_k[:, 0]), f"field {f}"
+        ref = orc.holo_generator(hp, amp[f:f + 1].repeat(8, 1, 1, 1), ph[f:f + 1].repeat(8, 1, 1, 1), dist.view(8, 1, 1, 1),
+                                 complex_number=True)
+        got = torch.polar(a_s[f], p_s[f]).unsqueeze(1)
+        assert cplx_rel(got, ref) < 1e-5, f"field {f}"
+        assert rel_err(i_s[f].cpu().unsqueeze(1), ref.abs() ** 2) < 2e-5, f"field {f}"
+
+
+def test_config5_red_blood_cell_sweep(dev, hg):
+    """BASELINE configs[4] end to end on one 1024x1024 frame: field retrieval with the red_blood_cell style vector, then
+    the 8-distance sweep of the retrieved field; the sweep of the NETWORK's output against the oracle's propagator fed the
+    same amplitude / phase (1e-5), and against the one-distance-at-a-time path (bit-exact)."""
+    import os
+    from conftest import REPO
+    from hip_helpers import build_network, cplx_rel, orc
+    from style_transfer_based_holographic_imaging_amd import synth
+    from utils.functions import field_retrieval
+    network, _ = build_network(0)
+    style = torch.load(os.path.join(REPO, "style_representation", "red_blood_cell", "style_vector.pt"), map_location="cpu").float()
+    ph = synth.synthetic_phase_objects(1, 1024, seed=1237)
+    d_c = synth.synthetic_distances(1, seed=1237)
+    dist = torch.linspace(-0.1, -0.8, 8)
+    with torch.no_grad():
+        content = torch.sqrt(hg(torch.full_like(ph, 0.6).to(dev), ph.to(dev), d_c.to(dev)))
+        amp, p, d = field_retrieval(network, content, style.to(dev), 1.0, True)
+        assert torch.isfinite(amp).all() and torch.isfinite(p).all() and 0.0 < float(d) < 1.0
+        a_s, p_s = hg.sweep(amp, p * 1.0, dist)
+        for k in (0, 3, 7):
+            a_k, p_k = hg(amp, p * 1.0, dist[k].view(1, 1, 1, 1).to(dev), return_field=True)
+            assert torch.equal(a_s[:, k:k + 1], a_k) and torch.equal(p_s[:, k:k + 1], p_k)
+        ref = orc.holo_generator(orc.HoloParams(), amp.cpu().repeat(8, 1, 1, 1), p.cpu().repeat(8, 1, 1, 1),
+                                 dist.view(8, 1, 1, 1), complex_number=True)
+    assert cplx_rel(torch.polar(a_s[0], p_s[0]).unsqueeze(1), ref) < 1e-5
+
+
 @pytest.mark.parametrize("s,b,padded", [(40, 2, True), (100, 2, True), (36, 3, False), (25, 2, False), (6, 1, True)])
 def test_generic_sizes_against_oracle(hg, dev, s, b, padded):
     """Transform sides that are not powers of two (80, 200, 36, 25, 12) take the direct-DFT kernels."""

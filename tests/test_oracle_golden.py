@@ -142,3 +142,23 @@ def test_asm_two_channel_field(golden):
     r2 = orc.asm(o2, HP.wavelength, torch.tensor([1e-4, -3e-4]).view(-1, 1, 1, 1), HP.pixel_size, True)
     ref = torch.complex(g["c2_re"], g["c2_im"])
     assert rel_err(torch.view_as_real(r2.to(torch.complex64)), torch.view_as_real(ref)) < 2e-6
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
+def test_golden_recipe_reproduces_the_committed_vectors(tmp_path):
+    """tests/golden/make_golden.py (imports the reference) run at HEAD gives the committed .npz files bit for bit — the
+    recipe is part of the pin.  Own process: the script rebinds ``net`` / ``function`` / ``utils`` to the reference."""
+    import subprocess
+    import sys
+    import numpy as np
+    from conftest import GOLDEN, REPO
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "--out", str(tmp_path)], cwd=REPO,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) and len(names) == 5
+    for name in names:
+        new, old = np.load(tmp_path / name), np.load(os.path.join(GOLDEN, name))
+        assert sorted(new.files) == sorted(old.files), name
+        for k in old.files:
+            assert np.array_equal(new[k], old[k]), f"{name}:{k}"

@@ -99,14 +99,20 @@ def _load():
     if lib.holo_abi_version() != ABI_VERSION:
         raise HoloLibraryError(f"ABI version {lib.holo_abi_version()} != expected {ABI_VERSION}")
     # a library built from other sources (same symbols, e.g. another weight-packing layout) must not load silently —
-    # checked on every rank of a multi-process job.  HOLO_HIP_LIB (an explicitly chosen A/B build) opts out.
+    # checked on every rank of a multi-process job.  HOLO_HIP_LIB (an explicitly chosen A/B build) opts out; an install
+    # that ships the library without csrc/ has nothing to compare with and says so.  The ROCm version is not part of the
+    # comparison (build.needs_build() uses it to decide on a REbuild).
     if not os.environ.get("HOLO_HIP_LIB"):
         from . import build as _build
-        built, here = lib.holo_source_hash().decode(), _build.source_hash()
-        if built != here:
-            raise HoloLibraryError(
-                f"{LIB_PATH} was built from other sources (library {built[:12]}, tree {here[:12]}): rebuild it "
-                "(python -c 'import __graft_entry__ as g; g.build()')")
+        if not _build.sources_present():
+            import warnings
+            warnings.warn(f"{LIB_PATH}: csrc/ is not present, the library's source hash cannot be checked", RuntimeWarning)
+        else:
+            built, here = lib.holo_source_hash().decode(), _build.source_hash()
+            if built != here:
+                raise HoloLibraryError(
+                    f"{LIB_PATH} was built from other sources (library {built[:12]}, tree {here[:12]}): rebuild it "
+                    "(python -c 'import __graft_entry__ as g; g.build()')")
     return lib
 
 

@@ -863,8 +863,8 @@ static int launch_asm(const AsmArgs& a) {
     const size_t row_lds_f = (size_t)(tw_entries_fwd<P>() + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
     const size_t row_lds_i = (size_t)(tw_entries_inv<P>() + SEQ * (fft_padded_len(P) + 1)) * sizeof(float2);
     const size_t col_lds = C::LDS;
-    static unsigned long long attr_done = 0;  // per device; idempotent, a race only repeats the call
-    if (first_call_on_device(attr_done)) {
+    static DeviceOnce attr_once;  // per device, published after the attributes are set
+    attr_once.run([&] {
         if (col_lds > 48 * 1024)
         {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_kernel<P, PAD>),
@@ -878,7 +878,7 @@ static int launch_asm(const AsmArgs& a) {
         if (row_lds_i > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
-    }
+    });
     const long rows_in = (long)a.n_fields * S;
     hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kRowThreads),
                        row_lds_f, a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale,
@@ -911,8 +911,8 @@ static int launch_asm_t(const AsmArgs& a) {
     using C = ColTCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
     const size_t row_lds_f = R::lds(tw_entries_fwd<P>()), row_lds_i = R::lds(tw_entries_inv<P>());
-    static unsigned long long attr_done = 0;  // per device
-    if (first_call_on_device(attr_done)) {
+    static DeviceOnce attr_once;  // per device, published after the attributes are set
+    attr_once.run([&] {
         if (C::LDS > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_t_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
@@ -922,7 +922,7 @@ static int launch_asm_t(const AsmArgs& a) {
         if (row_lds_i > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_t_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
-    }
+    });
     const long blocks_in = (long)a.n_fields * S / kTileRows;
     // transfer-function tables: extra blocks of the row kernel (blocks of the smallest grids have fewer than 64 threads: no table)
     const int n_out = a.n_fields * a.n_dist;

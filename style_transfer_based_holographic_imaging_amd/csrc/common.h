@@ -1,8 +1,10 @@
 // Shared host/device helpers for the holo_hip C-ABI library (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include "../../include/holo_hip.h"
 
 namespace holo {
@@ -28,28 +30,41 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Per-device one-time set-up (hipFuncSetAttribute for > 48 KB of dynamic LDS is a property of the function ON A DEVICE):
-// `mask` is a function-local static bit set of the devices already prepared.  A race only repeats the idempotent call.
-inline bool first_call_on_device(unsigned long long& mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: set the attributes every time
-    const unsigned long long bit = 1ull << dev;
-    if (mask & bit) return false;
-    mask |= bit;
-    return true;
-}
+// Per-device one-time set-up (hipFuncSetAttribute for > 48 KB of dynamic LDS is a property of the function ON A DEVICE).
+// `run(f)` executes f at most once per device and publishes the device's bit only AFTER f has returned (release), under a
+// mutex: a second host thread on the same device either sees the bit (acquire: the attributes are set) or waits for the
+// first one to finish — it can never launch ahead of the set-up.  One static instance per launcher.
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    std::mutex mu;
+    template <class F>
+    void run(F&& f) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) {   // unknown device: do the (idempotent) set-up every time
+            std::lock_guard<std::mutex> lk(mu);
+            f();
+            return;
+        }
+        const unsigned long long bit = 1ull << dev;
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        f();
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 // compute units of the current device (cached per device; 256 on MI355X): sizes persistent grids
 inline int device_cus() {
-    static int n_cu[64];
+    static std::atomic<int> n_cu[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
-    if (n_cu[dev] <= 0) {
-        int cus = 0;
+    int cus = n_cu[dev].load(std::memory_order_relaxed);
+    if (cus <= 0) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        n_cu[dev] = cus;
+        n_cu[dev].store(cus, std::memory_order_relaxed);
     }
-    return n_cu[dev];
+    return cus;
 }
 
 // tile selection of the 3x3 / transposed convolutions: 0 = automatic (shipped), 1..3 force a variant (holo_debug_set_conv_tile,

@@ -672,10 +672,12 @@ static int launch_conv(const T* x, const T* wp, const float* bias, T* y, int bat
     const int tiles_x = ceil_div(w, kPW), tiles_y = ceil_div(h, C::PR);
     const long blocks = (long)batch * tiles_x * tiles_y * (n / C::TN);
     HOLO_REQUIRE(blocks > 0 && blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "conv: grid of %ld blocks", blocks);
-    static unsigned long long attr_done = 0;   // per device
-    if (C::LDS_BYTES > 48 * 1024 && first_call_on_device(attr_done))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, CONVT, KC, T, WTM, WTN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    static DeviceOnce attr_once;   // per device, published after the attribute is set
+    if (C::LDS_BYTES > 48 * 1024)
+        attr_once.run([] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, CONVT, KC, T, WTM, WTN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        });
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, CONVT, KC, T, WTM, WTN>), dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES,
                        stream, x, wp, bias, y, h, w, cin, cout, n, tiles_x, tiles_y, relu, pool);
     return check_launch(CONVT ? "holo_convt2x2" : "holo_conv3x3");

@@ -555,20 +555,14 @@ int holo_conv3x3_wino_f32(const float* x_nhwc, const float* w_packed, const floa
     const int tiles_x = ceil_div(w, wino::kPW), tiles_y = ceil_div(h, wino::kPH);
     const long blocks = (long)batch * tiles_x * tiles_y * (cout / wino::kTN);
     HOLO_REQUIRE(blocks > 0 && blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_wino_f32: grid of %ld blocks", blocks);
-    static unsigned long long attr_done = 0;   // per device
-    static int n_cu[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (first_call_on_device(attr_done)) {
+    static DeviceOnce attr_once;   // per device, published after the attribute is set
+    attr_once.run([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, wino::kLdsBytes);
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        if (dev >= 0 && dev < 64) n_cu[dev] = cus;
-    }
+    });
     // persistent grid: one block per CU (512 registers per lane, 142 KB of LDS), tiles dealt round-robin.  Every block
     // runs to completion on its own (no inter-block waits), so a grid larger than the resident set would also be correct.
-    const int cus = (dev >= 0 && dev < 64 && n_cu[dev] > 0) ? n_cu[dev] : 256;
+    const int cus = device_cus();
 #if WINO_ABL & 8
     const long grid = blocks;
 #else

@@ -102,8 +102,17 @@ class Plan:
 
     # Winograd blocks are 32 x 16 pixels x 32 channels, one per CU (256 of them): measured over batch 1..64 at 128^2 and 256^2
     # (scripts/algo_sweep.sh) it wins from about half a wave of blocks up; below that the direct kernel's smaller tiles
-    # fill the chip better
+    # fill the chip better.  The two kernels differ by fp32 rounding (3e-5 of the outputs at 256^2), so the choice must not
+    # follow the exact batch size — a hologram would change with the shard it arrives in.  "auto" therefore decides from
+    # PER-IMAGE quantities (H, W, Cout) and a coarse batch BUCKET (1, 4 or 16 holograms: the largest of these not above
+    # the batch): every batch of 16 or more — all shards of a multi-GPU job, every micro-batch of the bench — makes the
+    # same choice, and so do all batches inside [4, 16) and inside [1, 4).
     WINO_MIN_BLOCKS = 128
+    BATCH_BUCKETS = (16, 4, 1)
+
+    @classmethod
+    def batch_bucket(cls, b):
+        return next((k for k in cls.BATCH_BUCKETS if b >= k), 1)
 
     def _use_winograd(self, step, x):
         if self.dtype != torch.float32 or step.kind != "conv" or self.conv_algo == "direct" or step.conv.in_channels < 32:
@@ -111,7 +120,8 @@ class Plan:
         if self.conv_algo == "winograd":
             return True
         b, h, w, _ = x.shape
-        return b * ((h + 31) // 32) * ((w + 15) // 16) * (step.conv.out_channels // 32) >= self.WINO_MIN_BLOCKS
+        per_image = ((h + 31) // 32) * ((w + 15) // 16) * (step.conv.out_channels // 32)
+        return self.batch_bucket(b) * per_image >= self.WINO_MIN_BLOCKS
 
     def _weights(self, idx, step, wino=False):
         conv = step.conv

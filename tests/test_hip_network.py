@@ -124,8 +124,7 @@ def test_full_size_properties(env, mnist_style):
     d_c = synth.synthetic_distances(8, seed=1234).to(dev)
     with torch.no_grad():
         content = torch.sqrt(hg(torch.full_like(ph, 0.6), ph, d_c))
-        # bit-exact for a FIXED convolution algorithm; "auto" picks Winograd or the direct kernel per launch from the number
-        # of blocks (batch included), like a vendor library's heuristics, so across batch sizes it is exact only to fp32 rounding
+        # bit-exact for a FIXED convolution algorithm
         try:
             for algo in ("direct", "winograd"):
                 network.set_conv_algo(algo)
@@ -134,9 +133,14 @@ def test_full_size_properties(env, mnist_style):
                 assert torch.equal(amp[2:5], amp2) and torch.equal(p[2:5], p2) and torch.equal(dist[2:5], dist2), algo
         finally:
             network.set_conv_algo("auto")
+        # "auto": the choice follows per-image quantities and a coarse batch bucket (engine.Plan.BATCH_BUCKETS: 1 / 4 / 16), so
+        # batches of 8 and 5 holograms (one bucket) agree bit for bit; across a bucket edge (8 vs 3) the two algorithms'
+        # fp32 rounding shows, measured 3.4e-5
         amp, p, dist = network.field_retrieval(content, mnist_style.to(dev), 1.0, True)
+        amp5, p5, dist5 = network.field_retrieval(content[2:7], mnist_style.to(dev), 1.0, True)
+        assert torch.equal(amp[2:7], amp5) and torch.equal(p[2:7], p5) and torch.equal(dist[2:7], dist5)
         amp2, p2, dist2 = network.field_retrieval(content[2:5], mnist_style.to(dev), 1.0, True)
-        assert rel_err(amp2.cpu(), amp[2:5].cpu()) < TOL and rel_err(p2.cpu(), p[2:5].cpu()) < TOL   # measured 3.4e-5
+        assert rel_err(amp2.cpu(), amp[2:5].cpu()) < 5e-5 and rel_err(p2.cpu(), p[2:5].cpu()) < 5e-5
         a0, p0 = network.field_retrieval(content[:2], mnist_style.to(dev), 0.0)
         direct = network.decoder(network.encode(content[:2]))
         assert torch.equal(direct[:, :1], a0) and torch.equal(direct[:, 1:], p0)

@@ -12,7 +12,10 @@ Default workload = BASELINE.json configs[1]: batch 64 per GPU, 256x256, fp32.
          --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU; every rank runs its own batch (weak scaling, no data-path collective)
-and the packed outputs are gathered to rank 0 with one RCCL gather per step, inside the timed region.
+and the packed outputs are gathered to rank 0 with one gather per step (RCCL on the GPU node), inside the timed region.
+--total N: BASELINE configs[3] as written — a FIXED total of N holograms (2048 there) sharded by
+shard.shard_bounds over the ranks, each rank looping micro-batches of --batch over its block, ONE gather of the
+rank's packed block per step (= one pass over all N holograms), "scaling": "strong".
 Rank 0 prints one JSON line.  `roofline` is the fp32-MFMA convolution kernel (the dominant kernel),
 `roofline_propagator` the HBM-bound angular-spectrum propagator; both from HIP events recorded on the
 launch stream during the timed steps.  `cpu_baseline` times the CPU oracle (a port of the reference's
@@ -113,7 +116,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="holograms per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="holograms per GPU per step (with --total: the micro-batch)")
+    ap.add_argument("--total", type=int, default=0,
+                    help="strong scaling (BASELINE configs[3]): a fixed total of N holograms per step, sharded over the ranks "
+                         "(contiguous blocks), processed in micro-batches of --batch, one gather of each rank's block")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=4, help="holograms in the CPU baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
@@ -161,25 +167,49 @@ def main():
     style_cpu = torch.load(os.path.join(REPO, "style_representation", args.style, "style_vector.pt"), map_location="cpu").float()
     style = style_cpu.to(dev)
 
-    # synthetic input, SURVEY.md §8d config 2: phase objects -> holograms by forward propagation (on the GPU)
+    # synthetic input, SURVEY.md §8d config 2 / 4: phase objects -> holograms by forward propagation (on the GPU)
     b, s = args.batch, args.size
-    seed = 1234 + rank
-    ph = synth.synthetic_phase_objects(b, s, seed=seed).to(dev)
-    d_content = synth.synthetic_distances(b, seed=seed).to(dev)
-    d_style = torch.full((b, 1, 1, 1), 0.2, device=dev)
-    with torch.no_grad():
-        content = torch.sqrt(model_forward(torch.full_like(ph, 0.6), ph, d_content)).contiguous()
-    del ph
+    if args.total:
+        if args.distances != 1:
+            raise SystemExit("--total runs the one-distance path (configs[3])")
+        # config 4: hologram i of the job is a function of i alone (chunks of 64 seeded 1236 + chunk), whatever the rank count
+        lo, hi = shard.shard_bounds(args.total, world, rank)
+        seed = 1236
+        chunks = []
+        for c in range(lo // 64, (max(hi, lo + 1) - 1) // 64 + 1):
+            c_lo = max(lo, 64 * c) - 64 * c
+            c_hi = min(hi, 64 * c + 64) - 64 * c
+            ph_c = synth.synthetic_phase_objects(64, s, seed=seed + c)[c_lo:c_hi].to(dev)
+            d_c = synth.synthetic_distances(64, seed=seed + c)[c_lo:c_hi].to(dev)
+            with torch.no_grad():
+                chunks.append(torch.sqrt(model_forward(torch.full_like(ph_c, 0.6), ph_c, d_c)))
+        content = torch.cat(chunks, 0).contiguous() if chunks else torch.empty((0, 1, s, s), device=dev)
+        del chunks
+        n_local = hi - lo
+        d_style = torch.full((max(b, 1), 1, 1, 1), 0.2, device=dev)
+        block = torch.empty((n_local, shard.packed_width(s)), dtype=torch.float32, device=dev)
+    else:
+        seed = 1234 + rank
+        ph = synth.synthetic_phase_objects(b, s, seed=seed).to(dev)
+        d_content = synth.synthetic_distances(b, seed=seed).to(dev)
+        d_style = torch.full((b, 1, 1, 1), 0.2, device=dev)
+        with torch.no_grad():
+            content = torch.sqrt(model_forward(torch.full_like(ph, 0.6), ph, d_content)).contiguous()
+        del ph
 
     sweep_d = torch.linspace(-0.1, -0.8, max(args.distances, 2), device=dev)[:args.distances]
 
-    def step():
+    def one_batch(x, d_st):
+        amp, p, d = field_retrieval(network, x, style, 1.0, True)
+        if args.distances > 1:   # utils/Data_loader.py:59-62 idiom: one field, a list of distances
+            a_f, p_f = model_forward.sweep(amp, p * 1.0, sweep_d)
+        else:
+            a_f, p_f = model_forward(amp, p * 1.0, -d_st, return_field=True, unwrap=False)
+        return amp, p, d, a_f, p_f
+
+    def step_weak():
         with torch.no_grad():
-            amp, p, d = field_retrieval(network, content, style, 1.0, True)
-            if args.distances > 1:   # utils/Data_loader.py:59-62 idiom: one field, a list of distances
-                a_f, p_f = model_forward.sweep(amp, p * 1.0, sweep_d)
-            else:
-                a_f, p_f = model_forward(amp, p * 1.0, -d_style, return_field=True, unwrap=False)
+            amp, p, d, a_f, p_f = one_batch(content, d_style)
             if world > 1 and args.distances == 1:
                 # the step's one exchange: started here, waited for one step later, so it rides under the next
                 # step's kernels; sync() drains the last one inside the timed region
@@ -187,6 +217,23 @@ def main():
                 if len(pending) > 1:
                     pending.pop(0).wait()
         return amp, p, d, a_f, p_f
+
+    def step_strong():
+        # one pass over the job's N holograms: this rank's block in micro-batches, then ONE gather of the packed block
+        last = []
+
+        def process(m0, m1, rows):
+            out = one_batch(content[m0 - lo:m1 - lo], d_style[:m1 - m0])
+            shard.pack_outputs(out[0], out[1], out[3], out[4], out[2], out=rows)
+            last[:] = [out]
+
+        with torch.no_grad():
+            if pending:                      # the block buffer is reused: the previous pass's gather must have left it
+                pending.pop(0).wait()
+            pending.append(shard.sharded_pass(args.total, b, process, shard.packed_width(s), dev, async_op=True, block=block))
+        return last[0] if last else None
+
+    step = step_strong if args.total else step_weak
 
     pending = []
 
@@ -235,16 +282,20 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        total = b * world * args.steps
+        total = (args.total if args.total else b * world) * args.steps
+        coll = {"nccl": "RCCL"}.get(backend, backend) if world > 1 else "none (single rank)"
+        cfg_no = 3 if args.total else (2 if args.dtype == "bf16" else 1)
+        per_gpu = f"{args.total} holograms in all, contiguous blocks of {-(-args.total // world)} per GPU in micro-batches of {b}" if args.total else f"batch {b}/GPU"
         out = {
             "metric": "holograms/sec (256x256 complex field retrieval)" if s == 256 else f"holograms/sec ({s}x{s} complex field retrieval)",
             "value": round(total / elapsed, 2), "unit": "holograms/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{2 if args.dtype == 'bf16' else 1}]: batch {b}/GPU synthetic {s}x{s} holograms, "
+            "scaling": "strong" if args.total else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{cfg_no}]: {per_gpu}, synthetic {s}x{s} holograms, "
                                    f"{ {'f32': 'fp32', 'bf16': 'bf16 convs / fp32 FFT', 'f32s': 'convs on split-fp16 operands (hi + lo*2^-11, fp32 accumulate; NOT fp32 arithmetic) / fp32 FFT'}[args.dtype] }, VGG-AdaIN-decoder + "
                                    f"distance head + angular-spectrum back-propagation (P={2 * s}), seeded He-normal weights",
-                       "batch_per_gpu": b, "size": s, "distances_per_field": args.distances, "style": args.style, "hipgraph": bool(args.graph), "conv_algo": args.conv_algo, "parallelism": f"batch-sharded x{world}, one RCCL gather per step"},
+                       "batch_per_gpu": b, "size": s, "distances_per_field": args.distances, "style": args.style, "hipgraph": bool(args.graph), "conv_algo": args.conv_algo, "total_holograms": args.total or b * world,
+                       "parallelism": f"batch-sharded x{world}, one {coll} gather per step" if world > 1 else "single GPU"},
         }
         if timer is not None:
             summ = timer.summary()
@@ -258,21 +309,32 @@ def main():
                 fl = sum(r["flops"] for r in conv)
                 ms = sum(r["ms"] for r in conv)
                 calls = sum(r["calls"] for r in conv)
-                ach = fl / (ms * 1e-3) / 1e12
+                alg = fl / (ms * 1e-3) / 1e12
+                # Winograd F(2x2,3x3) executes 16 multiplications per 2x2 output tile and channel pair where the direct
+                # convolution needs 36: `achieved` / `frac` describe the FLOP the kernel EXECUTES on the matrix pipe (a fraction
+                # of peak <= 1); the direct-convolution-equivalent ("algorithmic") rate is reported beside it
+                ach = alg * 16.0 / 36.0 if wino else alg
                 out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": traffic_conv, "traffic_source": traffic_src,
                                    "algorithmic_bytes_per_launch": round(sum(r["bytes"] for r in conv) / calls),
                                    "kernel": "conv_wino_f32_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, all large 3x3 layers)" if wino
                                    else f"conv_mfma_kernel<{args.dtype}> (3x3 + transposed, all layers)",
                                    "launches_per_step": calls // args.steps, "avg_launch_ms": round(ms / calls, 4),
-                                   "gflop_per_launch": round(fl / calls / 1e9, 3)}
+                                   "gflop_per_launch": round(fl * (16.0 / 36.0 if wino else 1.0) / calls / 1e9, 3)}
                 if wino:
-                    # `achieved` counts the ALGORITHMIC FLOP of the direct convolution (2*9*Cin*Cout per pixel); the kernel
-                    # executes 16/36 of them on the matrix pipe, so its utilisation of the pipe is frac * 4/9
-                    out["roofline"]["executed_mfma_tflops"] = round(ach * 16.0 / 36.0, 2)
-                    out["roofline"]["executed_mfma_frac"] = round(ach * 16.0 / 36.0 / peak, 4)
-                    out["roofline"]["note"] = ("Winograd F(2x2,3x3): 16 multiplications per 2x2 output tile and channel pair instead of 36, "
-                                               "so the algorithmic rate may exceed the fp32 MFMA peak; executed_mfma_frac is the matrix-pipe utilisation")
+                    out["roofline"]["direct_conv_equivalent_tflops"] = round(alg, 2)
+                    out["roofline"]["direct_conv_equivalent_over_peak"] = round(alg / peak, 4)
+                    out["roofline"]["executed_mfma_frac"] = round(ach / peak, 4)
+                    out["roofline"]["note"] = ("achieved = executed MFMA FLOP (2*16*Cin*Cout per 2x2 output tile) / time; the same launches "
+                                               "counted as a direct convolution (2*36*Cin*Cout) give direct_conv_equivalent_tflops, which "
+                                               "may exceed the fp32 MFMA peak — that is the algorithm's gain, not pipe utilisation")
+                    rest = [summ[k] for k in (f"holo_conv3x3_{args.dtype}", f"holo_convt2x2_{args.dtype}") if k in summ]
+                    if rest:   # the launches that stay on the implicit-GEMM kernel (transposed convs, layers below the Winograd threshold)
+                        fl2, ms2, c2 = (sum(r[k] for r in rest) for k in ("flops", "ms", "calls"))
+                        out["roofline_conv_direct"] = {"bound": "mfma", "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "peak": peak,
+                                                       "unit": "TFLOP/s", "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / peak, 4),
+                                                       "kernel": "conv_mfma_kernel<f32> (transposed convs and 3x3 layers not on Winograd)",
+                                                       "launches_per_step": c2 // args.steps, "avg_launch_ms": round(ms2 / c2, 4)}
             if "holo_asm_propagate" in summ:
                 r = summ["holo_asm_propagate"]
                 gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9
@@ -282,9 +344,9 @@ def main():
                                               "kernel": "asm_rows_fwd + asm_cols + asm_rows_inv (80*S^2 B per field)",
                                               "avg_call_ms": round(r["ms"] / r["calls"], 4)}
             out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(summ.items())}
-            out["conv_stack_tflops_overall"] = round(FLOP_PER_PIXEL * s * s * b * args.steps / 1e12 /
+            out["conv_stack_tflops_overall"] = round(FLOP_PER_PIXEL * s * s * (n_local if args.total else b) * args.steps / 1e12 /
                                                      (sum(v["ms"] for k, v in summ.items() if "conv" in k) * 1e-3), 2)
-        if world == 1 and args.distances == 1:
+        if world == 1 and args.distances == 1 and not args.total:
             # the step after the metric's path (test_field_retrieval_mnist.py:126 unwrap=True): timed on its own,
             # outside the holograms/s region, which SURVEY.md §8d defines pre-unwrap.  Single rank only: nothing
             # after the timed region may issue a collective the other ranks do not join.
@@ -297,7 +359,7 @@ def main():
                 unwrap(p_f)
             torch.cuda.synchronize()
             out["unwrap_ms_per_batch"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
-        if world == 1 and args.dtype == "f32" and args.distances == 1:
+        if world == 1 and args.dtype == "f32" and args.distances == 1 and not args.total:
             # informational, after the timed region and never part of `value`: the same step in the opt-in f32s mode
             # (fp32 values as split fp16 halves on the fp16 matrix cores) with its deviation from this run's
             # fp32 outputs

@@ -36,11 +36,48 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
-def pack_outputs(amp, ph, amp_foc, ph_foc, distance):
-    """(B,1,S,S) x4 + (B,1,1,1) -> one (B, 4*S*S + 1) float32 buffer: a single message per rank."""
+def pack_outputs(amp, ph, amp_foc, ph_foc, distance, out=None):
+    """(B,1,S,S) x4 + (B,1,1,1) -> one (B, 4*S*S + 1) float32 buffer: a single message per rank.
+    ``out``: rows of a preallocated block to fill instead (the strong-scaling pass packs micro-batch by micro-batch)."""
     b = amp.shape[0]
-    return torch.cat([amp.reshape(b, -1), ph.reshape(b, -1), amp_foc.reshape(b, -1), ph_foc.reshape(b, -1),
-                      distance.reshape(b, 1)], dim=1).contiguous()
+    parts = [amp.reshape(b, -1), ph.reshape(b, -1), amp_foc.reshape(b, -1), ph_foc.reshape(b, -1), distance.reshape(b, 1)]
+    if out is None:
+        return torch.cat(parts, dim=1).contiguous()
+    return torch.cat(parts, dim=1, out=out)
+
+
+def packed_width(s: int) -> int:
+    return 4 * s * s + 1
+
+
+def micro_batches(lo: int, hi: int, micro_batch: int):
+    """Split the block [lo, hi) into ceil(n / micro_batch) near-equal pieces (sizes differ by at most one): no short tail,
+    so every piece of a block of >= 16 holograms falls in one batch bucket of the convolution-algorithm choice
+    (engine.Plan.BATCH_BUCKETS) and a hologram's arithmetic does not depend on where the block boundaries fall."""
+    n = hi - lo
+    if n <= 0:
+        return []
+    pieces = -(-n // max(1, micro_batch))
+    return [tuple(lo + v for v in shard_bounds(n, pieces, i)) for i in range(pieces)]
+
+
+def sharded_pass(n_total: int, micro_batch: int, process, width: int, device, dtype=torch.float32, async_op: bool = False,
+                 block=None):
+    """One pass over a FIXED total of ``n_total`` holograms (strong scaling; BASELINE configs[3]: 2048 holograms over
+    1/2/4/8 GPUs): this rank's contiguous block ``shard_bounds(n_total, world, rank)`` is processed in micro-batches —
+    ``process(m0, m1, out_rows)`` handles GLOBAL holograms [m0, m1) and writes their packed outputs into ``out_rows``
+    ((m1 - m0, width)) — and the block goes to rank 0 with ONE gather (ragged blocks allowed).  Returns what
+    ``gather_to_root`` returns.  No data-path collective besides that gather."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_bounds(n_total, world, rank)
+    if block is None:
+        block = torch.empty((hi - lo, width), dtype=dtype, device=device)
+    assert block.shape == (hi - lo, width)
+    for m0, m1 in micro_batches(lo, hi, micro_batch):
+        process(m0, m1, block[m0 - lo:m1 - lo])
+    counts = [shard_bounds(n_total, world, q)[1] - shard_bounds(n_total, world, q)[0] for q in range(world)]
+    return gather_to_root(block, counts, async_op=async_op)
 
 
 def unpack_outputs(packed, s):

@@ -40,7 +40,7 @@ def cplx_rel(a, b):
     return float((a - b).abs().max() / b.abs().max())
 
 
-def bf16_emulated_field_retrieval(content, style, sds, alpha=1.0):
+def bf16_emulated_field_retrieval(content, style, sds, alpha=1.0, stages=None):
     """CPU emulation of the bf16 conv path: weights and every activation that the HIP path stores as bf16
     are rounded to bf16 (fp32 math in between, as the MFMA accumulates), statistics / last layer / distance
     head in fp32.  Test infrastructure (uses the oracle's layer tables)."""
@@ -63,6 +63,8 @@ def bf16_emulated_field_retrieval(content, style, sds, alpha=1.0):
                 x = r(x)
         else:
             x = r(F.max_pool2d(x, 2, 2, 0, ceil_mode=True))                             # pool is fused before the store
+        if stages is not None and step[0] == "conv" and step[1] in (2, 9, 16, 29):
+            stages.append(x.clone())
     mean, std = orc.calc_mean_std(x)
     t = r(orc.adain_with_style_vector(x, style, alpha))
     y = t

@@ -160,8 +160,15 @@ def test_network_bf16_matches_bf16_emulation(mnist_style):
 
 def test_network_bf16_at_config3_size(mnist_style):
     """BASELINE configs[2] shape: one 512x512 hologram through the bf16 conv path (the kernels' large-image tiling: 64 x 64
-    ... 512 x 512 feature maps, every pooled / transposed layer), against the CPU bf16-rounding emulation and the fp32 path,
-    then back-propagated by the fp32 propagator (P = 1024) against the oracle's propagator on the same amplitude / phase."""
+    ... 512 x 512 feature maps, every pooled / transposed layer).
+
+    What can be asked (tests/diagnostics/bf16_size_probe.py, measured): the four encoder stages agree with the CPU
+    bf16-rounding emulation to one or two bf16 ulps (relative L2 <= 4e-3, max <= 7e-3) at 128^2, 256^2 and 512^2 alike — that
+    is the kernel check.  End to end this random He-normal network amplifies bf16 rounding decisions, MORE on the smooth
+    synthetic holograms than on the bundled ones: at 512^2 the emulation itself sits 0.31 (L2) from the fp32 oracle, the HIP
+    path 0.31 from HIP fp32 and 0.24 from the emulation.  So end to end the HIP bf16 result must be (i) no farther from
+    the emulation than bf16 arithmetic is from fp32, and (ii) as far from fp32 as the emulation is (within 15 %).  The fp32
+    propagator (P = 1024) on the bf16 path's amplitude / phase keeps 1e-5 against the oracle's propagator."""
     from hip_helpers import DEV, bf16_emulated_field_retrieval, build_network, cplx_rel, holo_generator, orc
     from style_transfer_based_holographic_imaging_amd import synth
     network, sds = build_network(0)
@@ -170,15 +177,18 @@ def test_network_bf16_at_config3_size(mnist_style):
     d_c = synth.synthetic_distances(1, seed=1235)
     d_s = torch.full((1, 1, 1, 1), 0.2)
     sv = mnist_style.to(DEV)
+    emu_stages = []
     with torch.no_grad():
         content = torch.sqrt(hg(torch.full_like(ph, 0.6).to(DEV), ph.to(DEV), d_c.to(DEV)))
         a32, p32, d32 = network.field_retrieval(content, sv, 1.0, True)
         network.set_compute_dtype(torch.bfloat16)
         a16, p16, d16 = network.field_retrieval(content, sv, 1.0, True)
+        stages = [f.float().cpu() for f in network.encode_with_intermediate(content)]
         a16b, p16b, d16b = network.field_retrieval(content.repeat(2, 1, 1, 1), sv, 1.0, True)
         fld = hg(a16, p16 * 1.0, -d_s.to(DEV), complex_number=True)
         network.set_compute_dtype(torch.float32)
-        ea, ep, ed = bf16_emulated_field_retrieval(content.cpu(), mnist_style, sds)
+        ea, ep, ed = bf16_emulated_field_retrieval(content.cpu(), mnist_style, sds, stages=emu_stages)
+        oa, op_, od = orc.net_field_retrieval(content.cpu(), mnist_style, *sds, 1.0, True)
         same_in = orc.holo_generator(orc.HoloParams(), a16.cpu(), p16.cpu(), -d_s, complex_number=True)
     assert a16.shape == (1, 1, 512, 512) and a16.dtype == torch.float32
     assert torch.isfinite(a16).all() and torch.isfinite(p16).all()
@@ -186,7 +196,11 @@ def test_network_bf16_at_config3_size(mnist_style):
 
     def l2(a, b):
         return float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
-    assert l2(a16, ea) < 0.1 and l2(p16, ep) < 0.1, (l2(a16, ea), l2(p16, ep))
+    assert [tuple(f.shape[1:]) for f in stages] == [(64, 512, 512), (128, 256, 256), (256, 128, 128), (512, 64, 64)]
+    for k, (got, want) in enumerate(zip(stages, emu_stages)):
+        assert l2(got, want) < 8e-3 and rel_err(got, want) < 1.6e-2, (k, l2(got, want), rel_err(got, want))   # measured 3.6e-3 / 6.9e-3 at enc_4
+    noise_a, noise_p = l2(ea, oa), l2(ep, op_)                      # bf16 arithmetic against fp32, CPU against CPU
+    assert l2(a16, ea) < noise_a and l2(p16, ep) < noise_p, (l2(a16, ea), noise_a, l2(p16, ep), noise_p)
+    assert abs(l2(a16, a32) - noise_a) < 0.15 * noise_a and abs(l2(p16, p32) - noise_p) < 0.15 * noise_p
     assert float((d16.cpu() - ed).abs().max()) < 5e-2
-    assert l2(a16, a32) < 0.12 and l2(p16, p32) < 0.12
     assert cplx_rel(fld, same_in) < 1e-5

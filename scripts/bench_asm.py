@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Propagator-only micro-benchmark: `python scripts/bench_asm.py [B] [S] [iters]` (run under rocprofv3
---kernel-trace --stats for the per-kernel split).  Prints achieved algorithmic GB/s (80*S^2 B per field)."""
+"""Propagator-only micro-benchmark: `python scripts/bench_asm.py [B] [S] [iters] [--dist N] [--check] [--eager]`
+(run under rocprofv3 --kernel-trace --stats for the per-kernel split).  Times hipGraph replays of one call (no host launch
+overhead in the figure) and prints achieved algorithmic GB/s ((24 + 56 * N) * S^2 B per field).  --check compares the first
+fields with the CPU oracle (test infrastructure, not part of the timed path)."""
+import argparse
+import faulthandler
 import os
 import sys
 import time
@@ -12,21 +16,90 @@ sys.path.insert(0, REPO)
 from bench import HoloParams  # noqa: E402  (the five optics attributes Holo_Generator reads)
 from utils.Forward_model import Holo_Generator  # noqa: E402
 
-b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-s = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+ap = argparse.ArgumentParser()
+ap.add_argument("b", nargs="?", type=int, default=64)
+ap.add_argument("s", nargs="?", type=int, default=256)
+ap.add_argument("iters", nargs="?", type=int, default=50)
+ap.add_argument("--dist", type=int, default=1)
+ap.add_argument("--check", action="store_true")
+ap.add_argument("--eager", action="store_true")
+args = ap.parse_args()
+b, s, iters = args.b, args.s, args.iters
 dev = torch.device("cuda:0")
 hg = Holo_Generator(HoloParams())
 g = torch.Generator().manual_seed(0)
 amp = (torch.rand(b, 1, s, s, generator=g) + 0.2).to(dev)
 ph = (torch.rand(b, 1, s, s, generator=g) * 6 - 3).to(dev)
 d = torch.full((b, 1, 1, 1), -0.2, device=dev)
+sweep = torch.linspace(-0.1, -0.8, max(args.dist, 2), device=dev)[:args.dist]
+
+
+def call():
+    if args.dist > 1:
+        return hg.sweep(amp, ph, sweep)
+    return hg(amp, ph, d, return_field=True)
+
+
+if args.check:
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import holo_oracle as orc
+    n = min(b, 3)
+    a_o, p_o = call()
+    for rep in range(3):           # repeated calls: slot reuse, warm L1 / L2 contents of the previous call
+        a_o, p_o = call()
+    got = torch.polar(a_o[:n], p_o[:n]).cpu().to(torch.complex128)
+    worst = 0.0
+    for k in range(args.dist):
+        dk = sweep[k].view(1, 1, 1, 1).expand(n, 1, 1, 1).cpu() if args.dist > 1 else d[:n].cpu()
+        ref = orc.holo_generator(orc.HoloParams(), amp[:n].cpu(), ph[:n].cpu(), dk, complex_number=True)
+        e = float((torch.view_as_real(got[:, k:k + 1]) - torch.view_as_real(ref)).abs().max() / torch.view_as_real(ref).abs().max())
+        worst = max(worst, e)
+    # and the LAST fields against the first ones' recipe on the device itself (all fields share the recipe only if equal inputs)
+    amp2, ph2 = amp.clone(), ph.clone()
+    amp2[:] = amp[:1]
+    ph2[:] = ph[:1]
+    amp_s, ph_s = amp, ph
+    amp, ph = amp2, ph2
+    a_e, p_e = call()
+    amp, ph = amp_s, ph_s
+    same = bool((a_e == a_e[:1]).all() and (p_e == p_e[:1]).all())
+    print(f"check B={b} S={s} dist={args.dist}: max rel err vs oracle {worst:.2e}; identical fields give identical outputs: {same}", flush=True)
+    # control block of the dataflow kernel (csrc/asm_propagate.hip FusedCtl, behind the 3 * 4096 * 8 B of generic tables)
+    from style_transfer_based_holographic_imaging_amd import ops
+    ops._ASM_KEEP_WORKSPACE[:] = [None]
+    call()
+    torch.cuda.synchronize()
+    ws = ops._ASM_KEEP_WORKSPACE[0]
+    ops._ASM_KEEP_WORKSPACE.clear()
+    p_side = 2 * s
+    if ws is not None and 32 <= p_side <= 1024:
+        ctl = ws[3 * 4096 * 8: 3 * 4096 * 8 + 64 + 512].view(torch.int32).cpu().tolist()
+        tick = [ctl[16 + 16 * x] for x in range(8)]
+        nloc = [ctl[16 + 16 * x + 1] - 1 for x in range(8)]
+        print(f"  ctl: next_field {ctl[0]} error {ctl[1]} tickets/XCD {tick} local fields/XCD {nloc}", flush=True)
+
 for _ in range(5):
-    hg(amp, ph, d, return_field=True)
+    call()
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(iters):
-    hg(amp, ph, d, return_field=True)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / iters
-print(f"B={b} S={s}: {dt * 1e6:.1f} us/call, {80.0 * s * s * b / dt / 1e9:.0f} GB/s algorithmic ({100 * 80.0 * s * s * b / dt / 8e12:.1f}% of 8 TB/s)")
+if args.eager:
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+else:
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(10):
+            keep = call()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(max(1, iters // 10)):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) * 1e-3 / (max(1, iters // 10) * 10)
+nbytes = (24.0 + 56.0 * args.dist) * s * s * b
+print(f"B={b} S={s} dist={args.dist}: {dt * 1e6:.1f} us/call, {nbytes / dt / 1e9:.0f} GB/s algorithmic ({100 * nbytes / dt / 8e12:.1f}% of 8 TB/s)")

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import numpy as np
 import torch
+import torch.utils.data
 
 # (child index, kind, Cin, Cout); kind: "c1" 1x1 conv, "c3" 3x3 conv, "ct" ConvTranspose2d k2 s2.
 VGG_CONVS = [
@@ -110,3 +111,30 @@ def synthetic_distances(batch: int, seed: int = 1234):
     rng = np.random.default_rng(seed + 1)
     d = rng.choice(np.array([0.4, 0.5, 0.6, 0.7, 0.8], np.float32), size=batch)
     return torch.from_numpy(d.astype(np.float32)).view(-1, 1, 1, 1)
+
+
+class SyntheticDigits(torch.utils.data.Dataset):
+    """Stand-in for ``torchvision.datasets.MNIST`` (absent offline): ``n`` seeded 28 x 28 digit-like blobs in [0, 1] with a
+    label, indexable like the dataset ``utils.Data_loader.mnist_loader(_test)`` draws its first shuffled batch from."""
+
+    def __init__(self, n: int = 256, side: int = 28, seed: int = 4321):
+        rng = np.random.default_rng(seed)
+        yy, xx = np.mgrid[0:side, 0:side].astype(np.float32)
+        imgs = np.zeros((n, 1, side, side), np.float32)
+        for i in range(n):
+            img = np.zeros((side, side), np.float32)
+            for _ in range(int(rng.integers(2, 5))):
+                cy, cx = rng.uniform(0.25, 0.75, 2) * side
+                sy, sx = rng.uniform(0.06, 0.2, 2) * side
+                img += rng.uniform(0.5, 1.0) * np.exp(-((yy - cy) ** 2 / (2 * sy**2) + (xx - cx) ** 2 / (2 * sx**2)))
+            img /= max(float(img.max()), 1e-6)
+            img[img < 0.1] = 0.0
+            imgs[i, 0] = img
+        self.images = torch.from_numpy(imgs)
+        self.labels = torch.from_numpy(rng.integers(0, 10, n).astype(np.int64))
+
+    def __len__(self):
+        return self.images.shape[0]
+
+    def __getitem__(self, i):
+        return self.images[i], int(self.labels[i])

@@ -28,9 +28,16 @@ class Holo_Generator(nn.Module):
         return ((d + self.distance_normalize_constant) * self.distance_normalize) * 1e-3
 
     def forward(self, amplitude, phase, d, return_field=False, complex_number=False, unwrap=False):
+        if phase.shape != amplitude.shape:
+            # the reference multiplies amplitude * exp(1j * phase): torch broadcasting applies (utils/Data_loader.py:59-62
+            # passes one amplitude plane with a phase batch); expanded views cost nothing, the kernels take a zero stride
+            try:
+                amplitude, phase = torch.broadcast_tensors(amplitude, phase)
+            except RuntimeError as e:
+                raise RuntimeError(f"amplitude {tuple(amplitude.shape)} / phase {tuple(phase.shape)} do not broadcast") from e
         b, c, s, s2 = amplitude.shape
-        if s != s2 or phase.shape != amplitude.shape:
-            raise RuntimeError(f"amplitude {tuple(amplitude.shape)} / phase {tuple(phase.shape)} must be equal and square")
+        if s != s2:
+            raise RuntimeError(f"amplitude {tuple(amplitude.shape)} / phase {tuple(phase.shape)} must be square")
         d = self._distance_m(d)
         if isinstance(d, torch.Tensor) and d.numel() > 1:
             if d.numel() != b:

@@ -27,6 +27,12 @@ constexpr int kFH = kFT + 2;       // halo side
 constexpr int kFK = 28;            // padded K
 constexpr int kFWS = 29;           // LDS row stride of the weights (odd: conflict-free column reads)
 
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                          const float* __restrict__ b0, const float* __restrict__ w1,
@@ -105,7 +111,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                     st[m * 64 + nt * 32 + r] = (T)val;
                 }
             }
-        __syncthreads();
+        // stage[wave] is private to this wave and the LDS unit executes one wave's DS instructions in order: a wave-local
+        // fence orders the transposing reads behind the writes — no block barrier, the four waves run their tiles
+        // independently (round 2 had two __syncthreads() per M tile here)
+        wave_lds_fence();
         // 32 pixels x 64 channels = 32 * 64 * sizeof(T) / 16 units of 16 bytes; a lane takes every 64th
         constexpr int UPP = 64 * (int)sizeof(T) / 16;    // units per pixel (16 fp32 / 8 bf16)
 #pragma unroll
@@ -116,11 +125,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                 *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(yimg + ((size_t)Y * W + X) * 64) + 16 * c) =
                     *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(st + m * 64) + 16 * c);
         }
-        __syncthreads();
+        wave_lds_fence();   // the next M tile overwrites the stage
     }
 }
 
 // 16x16 output pixels per block, 64 input channels staged in four 16-channel chunks (18x18 halo each).
+// The 2 x 64 x 9 weights are block-uniform: they are read straight from the OIHW tensor through the SCALAR cache
+// (s_load -> SGPR operands of the FMAs), 72 at a time (4 channels x 9 taps x 2 outputs).  Round 2 kept them in LDS: every
+// lane then fetched the same 16 bytes with a ds_read_b128, and the LDS return path moves a full 1 KiB per wave for a
+// broadcast too — 288 of a thread's 432 LDS reads, which made the layer LDS-bound (0.35 ms at batch 64 x 256^2 for a
+// 1.07 GB read) instead of read-bound.
 constexpr int kLT = 16;
 constexpr int kLH = kLT + 2;
 
@@ -129,7 +143,6 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ bias, float* __restrict__ y, int H,
                                                         int W, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float halo[kLH * kLH * 16];
-    __shared__ float wl[9 * 64 * 2];  // [tap][ci][co]
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
@@ -138,10 +151,6 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const T* __restrict__ x,
     const int img = bid / tiles_y;
     const int x0 = tx * kLT, y0 = ty * kLT;
     const T* __restrict__ xi = x + (size_t)img * H * W * 64;
-    for (int i = tid; i < 9 * 64 * 2; i += 256) {
-        const int co = i & 1, ci = (i >> 1) & 63, tap = i >> 7;
-        wl[i] = w[(co * 64 + ci) * 9 + tap];  // OIHW (2,64,3,3)
-    }
     const int lx = tid & 15, ly = tid >> 4;
     float acc0 = bias[0], acc1 = bias[1];
     for (int chunk = 0; chunk < 4; ++chunk) {
@@ -188,17 +197,22 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const T* __restrict__ x,
         }
         __syncthreads();
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int q = (ly + tap / 3) * kLH + lx + tap % 3;
-            const float* wt = &wl[(tap * 64 + chunk * 16) * 2];
+        for (int c = 0; c < 4; ++c) {
+            // OIHW (2,64,3,3): the 9 taps of (co, ci) are contiguous; ci = chunk*16 + 4c + k.  Uniform addresses: scalar loads.
+            const float* __restrict__ w0p = w + (size_t)(chunk * 16 + 4 * c) * 9;
+            const float* __restrict__ w1p = w0p + 64 * 9;
+            float4 v[9];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 v = *reinterpret_cast<const float4*>(&halo[q * 16 + ((c ^ ((q >> 2) & 3)) << 2)]);
-                const float* wc = wt + c * 8;
-                acc0 += v.x * wc[0]; acc1 += v.x * wc[1];
-                acc0 += v.y * wc[2]; acc1 += v.y * wc[3];
-                acc0 += v.z * wc[4]; acc1 += v.z * wc[5];
-                acc0 += v.w * wc[6]; acc1 += v.w * wc[7];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int q = (ly + tap / 3) * kLH + lx + tap % 3;
+                v[tap] = *reinterpret_cast<const float4*>(&halo[q * 16 + ((c ^ ((q >> 2) & 3)) << 2)]);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                acc0 += v[tap].x * w0p[tap];      acc1 += v[tap].x * w1p[tap];
+                acc0 += v[tap].y * w0p[9 + tap];  acc1 += v[tap].y * w1p[9 + tap];
+                acc0 += v[tap].z * w0p[18 + tap]; acc1 += v[tap].z * w1p[18 + tap];
+                acc0 += v[tap].w * w0p[27 + tap]; acc1 += v[tap].w * w1p[27 + tap];
             }
         }
     }

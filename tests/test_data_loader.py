@@ -60,7 +60,7 @@ def test_loaders_on_the_device():
     np.random.seed(11)
     s_h, c_h, d_s, d_c = mnist_loader_test(_Args, ds, d_list, d_list, hg, DEV)
     assert s_h.shape == c_h.shape == (6, 1, 92, 92) and s_h.device == DEV and s_h.dtype == torch.float32
-    assert d_s.shape == d_c.shape == (6, 1, 1, 1) and set(np.round(d_c.view(-1).cpu().numpy(), 2)) <= set(d_list)
+    assert d_s.shape == d_c.shape == (6, 1, 1, 1) and {round(float(v), 2) for v in d_c.view(-1).cpu()} <= set(d_list)
     # the same seeds through the pieces: first shuffled batch, two transform draws (content first), oracle propagation
     torch.manual_seed(11)
     np.random.seed(11)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 2
+#define HOLO_ABI_VERSION 3
 
 /* error codes */
 #define HOLO_OK 0
@@ -84,6 +84,16 @@ int holo_pack_conv3x3_wino_weight_f32(const float* w_oihw, float* w_packed, int 
 size_t holo_conv3x3_wino_packed_elems(int cout, int cin);
 int holo_conv3x3_wino_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc,
                           int batch, int h, int w, int cin, int cout, int relu, int pool, void* stream);
+/* The same layer for launches too small to fill the chip (small batches, the deep low-resolution layers: the bundled
+ * 5 x 128^2 case has 80 tiles for 256 CUs): split-K.  The Cin/16 channel chunks of every tile are dealt to `ksplit` work items
+ * (ksplit in [2,8], dividing Cin/16 into parts of at least 2 chunks); each writes raw partial sums into `workspace`
+ * (holo_conv3x3_wino_splitk_workspace_bytes = ksplit * B*H*W*Cout floats) and a second launch adds the partials in the fixed
+ * order 0, 1, ... with bias, ReLU and pooling — deterministic and independent of the batch a hologram arrives in.  Differs from
+ * holo_conv3x3_wino_f32 by fp32 rounding (the summation over channels is re-associated). */
+size_t holo_conv3x3_wino_splitk_workspace_bytes(int batch, int h, int w, int cout, int ksplit);
+int holo_conv3x3_wino_splitk_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc,
+                                 int batch, int h, int w, int cin, int cout, int relu, int pool, int ksplit,
+                                 float* workspace, size_t workspace_bytes, void* stream);
 
 /* ConvTranspose2d(Cin,Cout,k=2,s=2) -> [ReLU] (net.py:40,55,64).  x: NHWC (B,H,W,Cin);
  * y: NHWC (B,2H,2W,Cout).  Cin % 16 == 0, Cout % 64 == 0. */

@@ -39,6 +39,8 @@ SIGNATURES = {
     "holo_pack_conv3x3_wino_weight_f32": (_i, [_p, _p, _i, _i, _p]),
     "holo_conv3x3_wino_packed_elems": (_z, [_i, _i]),
     "holo_conv3x3_wino_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "holo_conv3x3_wino_splitk_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "holo_conv3x3_wino_splitk_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "holo_convt2x2_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "holo_conv_last_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_channel_mean_std_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
@@ -76,7 +78,7 @@ SIGNATURES = {
 
 ASM_IN_AMP_PHASE, ASM_IN_COMPLEX = 0, 1
 ASM_OUT_AMP_PHASE, ASM_OUT_INTENSITY, ASM_OUT_COMPLEX = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HoloLibraryError(RuntimeError):

@@ -114,9 +114,13 @@ __device__ __forceinline__ int slot_of(int hy, int hx) { return hy * kHW + (hx &
                      : "memory");                                                                         \
     }
 
+// ksplit > 1 (split-K, for launches that would leave most CUs idle): a tile's channel chunks are dealt to `ksplit` work
+// items, each summing nchunks / ksplit of them; item s writes its RAW partial outputs (no bias, no activation) to
+// y + s * part_stride, and holo_splitk_reduce_f32 adds the partials in the fixed order s = 0, 1, ... with bias, ReLU and
+// pooling.  The split index is one more dimension of the persistent tile id: the loop body is unchanged.
 __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
-    int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int total, int relu, int pool) {
+    int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int total, int relu, int pool, int ksplit, long part_stride) {
     using namespace wino;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_a = smem;                  // [2][kABytes]
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n_blk = Cout / kTN;
-    const int nchunks = Cin / 16;
+    const int nchunks_all = Cin / 16;            // chunks of the layer (stride of the packed weights)
+    const int nchunks = nchunks_all / ksplit;    // chunks one work item sums (the entry point checks divisibility)
 
     // ---- tiles ----------------------------------------------------------------------------------------------------
     // The grid is PERSISTENT: block b works on tiles b, b + gridDim.x, ... (one block per CU: 512 registers per lane).  A
@@ -135,11 +140,13 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): XCD c gets a contiguous range of tile ids, so that
     // the channel blocks of one patch (same halo) and neighbouring patches meet in one L2 at about the same time.
     // Bijective when the tile count is a multiple of 8; speed only.
-    struct Tile { int nb, img, y0, x0; };
+    struct Tile { int nb, img, y0, x0, ks; };
     auto decode = [&](int vb) {
         int bid = vb;
         if ((total & 7) == 0) bid = (vb & 7) * (total >> 3) + (vb >> 3);
         Tile t;
+        t.ks = bid % ksplit;                     // fastest: the work items of one tile share its halo in one L2
+        bid /= ksplit;
         t.nb = bid % n_blk;
         bid /= n_blk;
         t.x0 = (bid % tiles_x) * kPW;
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
         asm volatile("" : "+v"(li), "+v"(hsel), "+v"(wave));
         const int co0 = tl.nb * kTN + 4 * hsel;      // first channel of this lane's quad 0 (quad q: + 8q)
         const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
-        float* __restrict__ yimg = y + (size_t)tl.img * (pool ? (size_t)Ho * Wo : (size_t)H * W) * Cout;
+        float* __restrict__ yimg = y + (size_t)tl.ks * part_stride + (size_t)tl.img * (pool ? (size_t)Ho * Wo : (size_t)H * W) * Cout;
         const bool full = tl.y0 + kPH <= H && tl.x0 + kPW <= W;
         // A^T M A on whole accumulator tiles, ONE TILE AT A TIME.  The accumulators live in AGPRs and VALU instructions cannot
         // read those: a tile used by the VALU is copied to 16 VGPRs first.  Walking register by register over all 16 positions
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
         // the bias quads are requested first: their latency hides behind the accumulator reads and the transform
         float4 bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + co0 + 8 * q);
+        for (int q = 0; q < 4; ++q) bq[q] = bias ? *reinterpret_cast<const float4*>(bias + co0 + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);   // split-K partials carry no bias
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
         auto rd_tile = [&](const floatx16& t) {
             floatx16 v;
@@ -410,8 +417,8 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     int vb = blockIdx.x;
     Tile cur = decode(vb);
     make_plan(cur);
-    const float* __restrict__ ximg = x + (size_t)cur.img * H * W * Cin;
-    const float* __restrict__ wblk = wp + (size_t)cur.nb * nchunks * (kBBytes / 4);   // [nb][chunk][pos][co][16]
+    const float* __restrict__ ximg = x + (size_t)cur.img * H * W * Cin + (size_t)cur.ks * nchunks * 16;
+    const float* __restrict__ wblk = wp + ((size_t)cur.nb * nchunks_all + (size_t)cur.ks * nchunks) * (kBBytes / 4);   // [nb][chunk][pos][co][16]
 #pragma unroll
     for (int r = 0; r < kARounds; ++r) { WINO_LOAD_A_ROUND(ximg, 0, r, plan[r * kThreads]) }
 #pragma unroll
@@ -465,8 +472,8 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
 #if !(WINO_ABL & 4)
                 make_plan(nxt);
 #endif      // the current tile's plan issued its last round in q0 of the previous chunk
-                a_next = x + (size_t)nxt.img * H * W * Cin;
-                b_next = wp + (size_t)nxt.nb * nchunks * (kBBytes / 4);
+                a_next = x + (size_t)nxt.img * H * W * Cin + (size_t)nxt.ks * nchunks * 16;
+                b_next = wp + ((size_t)nxt.nb * nchunks_all + (size_t)nxt.ks * nchunks) * (kBBytes / 4);
             }
         }
         const unsigned char* abuf = lds_a + par * kABytes;
@@ -543,6 +550,48 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
+// split-K reduction: y = act(sum_s partial[s] + bias), partials added in the fixed order s = 0, 1, ... (bit-identical for a
+// pixel whatever the batch), then the optional MaxPool2d(2,2,ceil_mode=True) over the activated values
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long part_stride,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int batch,
+                                                           int H, int W, int C, int relu, int pool) {
+    const int Ho = pool ? (H + 1) >> 1 : H, Wo = pool ? (W + 1) >> 1 : W;
+    const int c4n = C >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * Ho * Wo * c4n) return;
+    const int c4 = (int)(idx % c4n);
+    long r = idx / c4n;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho);
+    const int img = (int)(r / Ho);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    auto pixel = [&](int yy, int xx) {
+        const float* p = part + (((size_t)img * H + yy) * W + xx) * C + 4 * c4;
+        float4 a = *reinterpret_cast<const float4*>(p);
+        for (int s2 = 1; s2 < ksplit; ++s2) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)s2 * part_stride);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        a.x += b4.x; a.y += b4.y; a.z += b4.z; a.w += b4.w;
+        if (relu) a = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+        return a;
+    };
+    float4 o;
+    if (!pool) {
+        o = pixel(yo, xo);
+    } else {
+        o = pixel(2 * yo, 2 * xo);
+        auto mx = [&](float4 v) { o = make_float4(fmaxf(o.x, v.x), fmaxf(o.y, v.y), fmaxf(o.z, v.z), fmaxf(o.w, v.w)); };
+        if (2 * xo + 1 < W) mx(pixel(2 * yo, 2 * xo + 1));
+        if (2 * yo + 1 < H) {
+            mx(pixel(2 * yo + 1, 2 * xo));
+            if (2 * xo + 1 < W) mx(pixel(2 * yo + 1, 2 * xo + 1));
+        }
+    }
+    *reinterpret_cast<float4*>(y + (((size_t)img * Ho + yo) * Wo + xo) * C + 4 * c4) = o;
+}
+
 }  // namespace holo
 
 #if WINO_STAMPS
@@ -598,8 +647,52 @@ int holo_conv3x3_wino_f32(const float* x_nhwc, const float* w_packed, const floa
     const long grid = blocks < cus ? blocks : cus;
 #endif
     hipLaunchKernelGGL(conv_wino_f32_kernel, dim3((unsigned)grid), dim3(wino::kThreads), wino::kLdsBytes, as_stream(stream),
-                       x_nhwc, w_packed, bias, y_nhwc, h, w, cin, cout, tiles_x, tiles_y, (int)blocks, relu, pool);
+                       x_nhwc, w_packed, bias, y_nhwc, h, w, cin, cout, tiles_x, tiles_y, (int)blocks, relu, pool, 1, 0L);
     return check_launch("holo_conv3x3_wino_f32");
+}
+
+size_t holo_conv3x3_wino_splitk_workspace_bytes(int batch, int h, int w, int cout, int ksplit) {
+    if (batch <= 0 || h <= 0 || w <= 0 || cout <= 0 || ksplit <= 0) return 0;
+    return (size_t)ksplit * batch * h * w * cout * sizeof(float);
+}
+
+int holo_conv3x3_wino_splitk_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc, int batch, int h,
+                                 int w, int cin, int cout, int relu, int pool, int ksplit, float* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc && workspace, HOLO_ERR_ARG, "holo_conv3x3_wino_splitk_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG,
+                 "holo_conv3x3_wino_splitk_f32: batch=%d h=%d w=%d (reflection padding needs h,w >= 2)", batch, h, w);
+    HOLO_REQUIRE(cin >= 32 && cin % 16 == 0 && cout > 0 && cout % 32 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_wino_splitk_f32: Cin=%d must be a multiple of 16 (at least 32) and Cout=%d a multiple of 32", cin, cout);
+    HOLO_REQUIRE(ksplit >= 2 && ksplit <= 8 && (cin / 16) % ksplit == 0 && (cin / 16) / ksplit >= 2, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_wino_splitk_f32: ksplit=%d must be in [2,8] and divide the %d channel chunks into parts of at least 2",
+                 ksplit, cin / 16);
+    HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_wino_splitk_f32: fused pooling requires relu");
+    HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < (1L << 30), HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_wino_splitk_f32: one image must stay below 2^30 elements (32-bit byte offsets)");
+    HOLO_REQUIRE(workspace_bytes >= holo_conv3x3_wino_splitk_workspace_bytes(batch, h, w, cout, ksplit), HOLO_ERR_WORKSPACE,
+                 "holo_conv3x3_wino_splitk_f32: workspace %zu < required %zu", workspace_bytes,
+                 holo_conv3x3_wino_splitk_workspace_bytes(batch, h, w, cout, ksplit));
+    const int tiles_x = ceil_div(w, wino::kPW), tiles_y = ceil_div(h, wino::kPH);
+    const long blocks = (long)batch * tiles_x * tiles_y * (cout / wino::kTN) * ksplit;
+    HOLO_REQUIRE(blocks > 0 && blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_wino_splitk_f32: grid of %ld blocks", blocks);
+    static DeviceOnce attr_once;   // per device, published after the attribute is set
+    attr_once.run([] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, wino::kLdsBytes);
+    });
+    const int cus = device_cus();
+    const long grid = blocks < cus ? blocks : cus;
+    const long part = (long)batch * h * w * cout;
+    hipLaunchKernelGGL(conv_wino_f32_kernel, dim3((unsigned)grid), dim3(wino::kThreads), wino::kLdsBytes, as_stream(stream),
+                       x_nhwc, w_packed, static_cast<const float*>(nullptr), workspace, h, w, cin, cout, tiles_x, tiles_y, (int)blocks,
+                       0, 0, ksplit, part);
+    const int ho = pool ? (h + 1) / 2 : h, wo = pool ? (w + 1) / 2 : w;
+    const long n4 = (long)batch * ho * wo * (cout / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), workspace, ksplit,
+                       part, bias, y_nhwc, batch, h, w, cout, relu, pool);
+    return check_launch("holo_conv3x3_wino_splitk_f32");
 }
 
 }  // extern "C"

@@ -114,14 +114,29 @@ class Plan:
     def batch_bucket(cls, b):
         return next((k for k in cls.BATCH_BUCKETS if b >= k), 1)
 
-    def _use_winograd(self, step, x):
+    # split-K (ops.conv3x3_wino(ksplit=...)): a layer short of blocks deals its channel chunks to 2, 4 or 8 work items per tile, each
+    # summing at least 4 chunks (64 channels); chosen, like the algorithm, from per-image quantities and the batch bucket
+    KSPLITS = (2, 4, 8)
+    KSPLIT_MIN_CHUNKS = 4
+
+    def _wino_choice(self, step, x):
+        """(use the Winograd kernel, ksplit) for a 3x3 step on input x (NHWC)."""
         if self.dtype != torch.float32 or step.kind != "conv" or self.conv_algo == "direct" or step.conv.in_channels < 32:
-            return False
+            return False, 1
         if self.conv_algo == "winograd":
-            return True
+            return True, 1
         b, h, w, _ = x.shape
-        per_image = ((h + 31) // 32) * ((w + 15) // 16) * (step.conv.out_channels // 32)
-        return self.batch_bucket(b) * per_image >= self.WINO_MIN_BLOCKS
+        blocks = self.batch_bucket(b) * ((h + 31) // 32) * ((w + 15) // 16) * (step.conv.out_channels // 32)
+        if blocks >= self.WINO_MIN_BLOCKS:
+            return True, 1
+        chunks = step.conv.in_channels // 16
+        for k in self.KSPLITS:
+            if chunks % k == 0 and chunks // k >= self.KSPLIT_MIN_CHUNKS and blocks * k >= self.WINO_MIN_BLOCKS:
+                return True, k
+        return False, 1
+
+    def _use_winograd(self, step, x):
+        return self._wino_choice(step, x)[0]
 
     def _weights(self, idx, step, wino=False):
         conv = step.conv
@@ -161,9 +176,11 @@ class Plan:
 
     def run_step(self, idx, x):
         st = self.steps[idx]
-        if st.kind == "conv" and x.dtype == torch.float32 and self._use_winograd(st, x):
-            wts = self._weights(idx, st, wino=True)
-            return ops.conv3x3_wino(x, wts[0], wts[1], st.conv.out_channels, st.relu, st.pool)
+        if st.kind == "conv" and x.dtype == torch.float32:
+            use_wino, ksplit = self._wino_choice(st, x)
+            if use_wino:
+                wts = self._weights(idx, st, wino=True)
+                return ops.conv3x3_wino(x, wts[0], wts[1], st.conv.out_channels, st.relu, st.pool, ksplit=ksplit)
         wts = self._weights(idx, st)
         if st.kind == "first":
             if x.dim() != 4 or x.shape[1] != 1:

@@ -281,9 +281,10 @@ def conv3x3(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, co
     return y
 
 
-def conv3x3_wino(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, relu=True, pool=False):
+def conv3x3_wino(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, relu=True, pool=False, ksplit: int = 1):
     """conv3x3 as fp32 Winograd F(2x2,3x3) (weights from pack_conv3x3_wino).  FLOP are counted as the direct
-    convolution's (the algorithmic work), so a rate above the fp32 MFMA peak is the algorithm's gain."""
+    convolution's (the algorithmic work), so a rate above the fp32 MFMA peak is the algorithm's gain.
+    ``ksplit`` > 1: split-K for launches that would leave most of the chip idle (holo_conv3x3_wino_splitk_f32)."""
     _req(x_nhwc, w_packed, bias)
     b, h, w, cin = x_nhwc.shape
     if x_nhwc.dtype != torch.float32 or w_packed.dtype != torch.float32:
@@ -291,6 +292,14 @@ def conv3x3_wino(x_nhwc: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tenso
     x_nhwc = _actc(x_nhwc)
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
     y = torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x_nhwc.device)
+    if ksplit > 1:
+        ws_bytes = lib.holo_conv3x3_wino_splitk_workspace_bytes(b, h, w, cout, int(ksplit))
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x_nhwc.device)
+        _launch("holo_conv3x3_wino_splitk_f32", lambda: lib.holo_conv3x3_wino_splitk_f32(
+            x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, cin, cout, int(relu), int(pool), int(ksplit),
+            ws.data_ptr(), ws_bytes, _stream()),
+                flops=2.0 * 9 * cin * cout * b * h * w, nbytes=4.0 * b * (h * w * cin + ho * wo * cout))
+        return y
     _launch("holo_conv3x3_wino_f32", lambda: lib.holo_conv3x3_wino_f32(x_nhwc.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                                                      b, h, w, cin, cout, int(relu), int(pool), _stream()),
             flops=2.0 * 9 * cin * cout * b * h * w, nbytes=4.0 * b * (h * w * cin + ho * wo * cout))
@@ -403,7 +412,8 @@ def distance_head(mean, std, sd):
 # angular spectrum
 # ---------------------------------------------------------------------------------------------
 # fields per launch group: keeps the two S x P complex64 intermediates inside the 256 MiB Infinity Cache
-_ASM_CACHE_BUDGET = 160 << 20
+import os as _os
+_ASM_CACHE_BUDGET = int(_os.environ.get("HOLO_ASM_GROUP_MB", "320")) << 20      # (the variable is a tuning knob for scripts/bench_asm.py)
 _ASM_KEEP_WORKSPACE = []      # diagnostics: a non-empty list receives the workspace tensor of the last call
 
 
@@ -479,6 +489,7 @@ def asm_propagate(in0, in1, phase_c, s, zero_padding, wavelength, pixel_size, ph
     p = 2 * s if zero_padding else s
     per_field = s * p * 8 * (1 + n_dist)
     group = max(1, min(n_fields, _ASM_CACHE_BUDGET // per_field, 65535 // n_dist))
+    group = -(-n_fields // -(-n_fields // group))      # near-equal groups: 64 fields at 20 per group run as 4 x 16, not 20 + 20 + 20 + 4
     ws_bytes = lib.holo_asm_workspace_bytes(group, n_dist, s, int(bool(zero_padding)))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     if _ASM_KEEP_WORKSPACE:

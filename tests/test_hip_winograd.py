@@ -146,11 +146,55 @@ def test_auto_picks_winograd_only_for_layers_that_fill_the_chip(dev):
     plan = Plan(list(net.decoder.children()))
     conv = next(s for s in plan.steps if s.kind == "conv")
     big = torch.empty(64, 32, 32, conv.conv.in_channels, device="meta")
-    small = torch.empty(5, 16, 16, conv.conv.in_channels, device="meta")
+    small = torch.empty(2, 16, 16, conv.conv.in_channels, device="meta")     # 16 blocks: not even split-K reaches half a wave
     assert plan._use_winograd(conv, big) and not plan._use_winograd(conv, small)
+    assert plan._wino_choice(conv, torch.empty(5, 16, 16, conv.conv.in_channels, device="meta")) == (True, 2)   # split-K instead
     plan.conv_algo = "direct"
     assert not plan._use_winograd(conv, big)
     plan.conv_algo = "winograd"
     assert plan._use_winograd(conv, small)
     plan.dtype = torch.bfloat16
     assert not plan._use_winograd(conv, big)
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,relu,pool,ksplit", [
+    (5, 32, 32, 256, 256, True, False, 2),     # the bundled shape's deep layers (5 x 128^2: 32 x 32 and 16 x 16 feature maps)
+    (5, 16, 16, 512, 256, True, False, 4),
+    (5, 16, 16, 256, 512, True, False, 2),
+    (3, 13, 21, 64, 64, True, True, 2),        # partial tiles, ceil-mode pooling in the reduction
+    (2, 5, 5, 128, 32, True, True, 4),
+    (1, 2, 2, 64, 64, False, False, 2),        # smallest legal image, no activation
+    (2, 40, 24, 256, 96, False, False, 8),     # 16 chunks in 8 parts of 2: the smallest part the entry point accepts
+])
+def test_conv3x3_winograd_splitk(ops, dev, b, h, w, cin, cout, relu, pool, ksplit):
+    """Split-K: the channel chunks of a tile dealt to `ksplit` work items + the fixed-order reduction (bias, ReLU, pooling in
+    the reduction).  Same accuracy bar as the un-split kernel against torch-CPU fp32; bit-identical per hologram whatever the
+    batch it arrives in."""
+    x, wt, bias = _case(h * 1000 + w + cin + ksplit, b, h, w, cin, cout)
+    ref = _ref(x, wt, bias, relu, pool)
+    xp = ops.to_nhwc(x.to(dev))
+    wp = ops.pack_conv3x3_wino(wt.to(dev))
+    y = ops.conv3x3_wino(xp, wp, bias.to(dev), cout, relu, pool, ksplit=ksplit)
+    got = ops.as_nchw_view(y).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < (6e-6 if cin >= 512 else 3e-6)
+    plain = ops.as_nchw_view(ops.conv3x3_wino(xp, wp, bias.to(dev), cout, relu, pool)).cpu()
+    assert rel_err(got, plain) < 2e-6                                   # re-associated sum over channels: rounding only
+    if b > 1:
+        one = ops.conv3x3_wino(xp[1:2].contiguous(), wp, bias.to(dev), cout, relu, pool, ksplit=ksplit)
+        assert torch.equal(one, y[1:2])
+
+
+def test_validation_winograd_splitk():
+    import ctypes
+    from style_transfer_based_holographic_imaging_amd._lib import lib
+    fake = ctypes.c_void_p(16)
+    big = 1 << 40
+    args = lambda cin, cout, k, ws=big: (fake, fake, fake, fake, 1, 4, 4, cin, cout, 1, 0, k, fake, ws, None)  # noqa: E731
+    assert lib.holo_conv3x3_wino_splitk_f32(None, fake, fake, fake, 1, 4, 4, 64, 32, 1, 0, 2, fake, big, None) == 1
+    assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 1)) == 2          # ksplit < 2
+    assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 3)) == 2          # 4 chunks do not divide by 3
+    assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 4)) == 2          # parts of one chunk
+    assert lib.holo_conv3x3_wino_splitk_f32(*args(96, 48, 2)) == 2          # Cout % 32
+    assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 2, 16)) == 3      # workspace
+    assert lib.holo_conv3x3_wino_splitk_workspace_bytes(5, 32, 32, 256, 2) == 2 * 5 * 32 * 32 * 256 * 4

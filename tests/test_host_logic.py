@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/holo_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), "ctypes SIGNATURES and the header disagree"
-    assert _lib.lib.holo_abi_version() == 2
+    assert _lib.lib.holo_abi_version() == 3
     assert _lib.lib.holo_target_arch() == b"gfx950"
 
 
@@ -297,3 +297,26 @@ def test_auto_conv_algo_does_not_follow_the_exact_batch():
                 assert len({pick(b) for b in (16, 17, 63, 64, 255, 256)}) == 1
                 assert len({pick(b) for b in (4, 5, 8, 15)}) == 1
                 assert len({pick(b) for b in (1, 2, 3)}) == 1
+
+
+def test_auto_splits_k_for_layers_short_of_blocks():
+    """engine.Plan: below the Winograd block threshold "auto" first tries split-K (2, 4 or 8 work items per tile, each summing
+    at least 4 chunks of 16 channels); only if that cannot reach the threshold does the layer stay on the direct kernel."""
+    import net
+    from style_transfer_based_holographic_imaging_amd.engine import Plan
+    plan = Plan(list(net.decoder.children()))
+    convs = [s for s in plan.steps if s.kind == "conv"]
+
+    def pick(cin, cout, b, side):
+        st = next(s for s in convs if (s.conv.in_channels, s.conv.out_channels) == (cin, cout))
+        return plan._wino_choice(st, torch.empty(b, side, side, cin, device="meta"))
+    assert pick(512, 512, 5, 16) == (True, 2)        # the bundled shape (5 x 128^2): 16 blocks per image x bucket 4 = 64 -> x2
+    assert pick(512, 256, 5, 16) == (True, 4)
+    assert pick(256, 256, 5, 32) == (True, 2)
+    assert pick(256, 128, 5, 32) == (True, 4)
+    assert pick(128, 128, 5, 64) == (True, 1)        # 128 blocks already
+    assert pick(256, 256, 64, 64) == (True, 1)       # the benchmark's batch: never split
+    assert pick(256, 256, 1, 32) == (False, 1)       # 16 blocks: even 8 parts of 2 chunks are not allowed -> direct kernel
+    assert pick(512, 512, 7, 16) == pick(512, 512, 4, 16) == pick(512, 512, 15, 16)     # one bucket, one choice
+    plan.conv_algo = "winograd"
+    assert pick(512, 512, 5, 16) == (True, 1)        # forced Winograd is the un-split kernel

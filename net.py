@@ -5,8 +5,8 @@ net.py:76-130) and ``decoder`` (38 children, net.py:33-74) with the reference's 
 ``Net(encoder, decoder, decoder_ph=None, distance_g=None)`` (net.py:133-260) and ``Distance_G()``
 (net.py:266-327).  The children are parameter holders; the arithmetic is the fused plan of
 ``style_transfer_based_holographic_imaging_amd.engine`` (NHWC fp32 MFMA convolutions, fused
-ReLU/pool epilogues).  Training-only pieces (``Net.forward`` losses, ``Discriminator``) are out of
-scope.  Tensors must live on a ROCm device: there is no CPU fallback.
+ReLU/pool epilogues).  ``Net.forward`` evaluates the training objective's forward values (no autograd: the HIP kernels have no
+backward pass); ``Discriminator`` is out of scope.  Tensors must live on a ROCm device: there is no CPU fallback.
 """
 import torch
 import torch.nn as nn
@@ -121,9 +121,52 @@ class Net(nn.Module):
     def encode(self, input):
         return self._public(self._encode(input))
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("Net.forward is the training-loss graph (net.py:199-226): out of scope for the "
-                                  "MI355X inference path; use field_retrieval()")
+    def calc_content_loss(self, input, target):
+        """net.py:186-189"""
+        assert (input.size() == target.size())
+        assert (target.requires_grad is False)
+        return self.mse_loss(input, target)
+
+    def calc_style_loss(self, input, target):
+        """net.py:191-197: MSE of the per-channel means plus MSE of the per-channel standard deviations"""
+        assert (input.size() == target.size())
+        assert (target.requires_grad is False)
+        input_mean, input_std = calc_mean_std(input)
+        target_mean, target_std = calc_mean_std(target)
+        return self.mse_loss(input_mean, target_mean) + self.mse_loss(input_std, target_std)
+
+    def forward(self, content, style, alpha=1.0, field_retrieval=False, unkonwn_distance=False):
+        """net.py:199-226: the training objective, FORWARD VALUES ONLY.  Same arguments (sic: ``unkonwn_distance``) and the
+        same 2 / 5 / 7 return values; every network pass runs on the HIP kernels (encoder on the style image and on the
+        generated amplitude, image-style AdaIN of function.py:15-23, two decoder passes, the distance head on both statistics);
+        the scalar MSE reductions are ``nn.MSELoss`` as in the reference.  The HIP kernels have no backward pass, so the
+        results carry no autograd graph: this evaluates the losses (validation curves, checkpoint comparison), it does not
+        train — optimising the decoder on MI355X is outside this build."""
+        assert 0 <= alpha <= 1
+        with torch.no_grad():
+            style_feats = self.encode_with_intermediate(style)
+            content_feat = self.encode(content)
+            # adain(content_feat, style_feats[-1]) and the alpha blend, in one launch (function.py:15-23, net.py:203-204)
+            x = ops.to_nhwc(content_feat)
+            s_mean, s_std = ops.channel_mean_std(ops.to_nhwc(style_feats[-1]))
+            c_mean, c_std = ops.channel_mean_std(x)
+            t = ops.as_nchw_view(ops.adain_apply(x, c_mean, c_std, s_mean, s_std, float(alpha)))
+            style_re = self.decoder(style_feats[-1])[:, :1]
+            g_t = self.decoder(t)                 # content diffraction pattern -> style diffraction pattern
+            g_t_phase = g_t[:, 1:]
+            g_t = g_t[:, :1]
+            g_t_feats = self.encode_with_intermediate(g_t)
+            loss_c = self.calc_content_loss(g_t_feats[-1], t)
+            loss_s = self.calc_style_loss(g_t_feats[0], style_feats[0])
+            for i in range(1, self.n_layer):
+                loss_s += self.calc_style_loss(g_t_feats[i], style_feats[i])
+            if field_retrieval:
+                if unkonwn_distance:
+                    d_content = self.distance_g(calc_mean_std(content_feat))
+                    d_style = self.distance_g(calc_mean_std(style_feats[-1]))
+                    return loss_c, loss_s, g_t, g_t_phase, style_re, d_content, d_style
+                return loss_c, loss_s, g_t, g_t_phase, style_re
+            return loss_c, loss_s
 
     def field_retrieval(self, content, style_feats, alpha=1.0, unknown_distance=False):
         assert 0 <= alpha <= 1

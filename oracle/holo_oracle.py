@@ -155,6 +155,38 @@ def net_field_retrieval(content, style_feats, vgg_sd, dec_sd, dist_sd=None, alph
     return amp, ph
 
 
+def _mse(a, b):
+    return ((a - b) ** 2).mean()
+
+
+def net_forward(content, style, vgg_sd, dec_sd, dist_sd=None, alpha=1.0, field_retrieval=False, unkonwn_distance=False):
+    """net.py:199-226 (Net.forward): the training objective's FORWARD values — content loss on relu4_1 of the generated
+    amplitude against the AdaIN target, style loss = mean/std MSE over the four encoder stages (net.py:186-197), and with
+    ``field_retrieval`` the generated amplitude / phase, the style reconstruction and (``unkonwn_distance``, sic) both
+    predicted distances."""
+    assert 0 <= alpha <= 1
+    style_feats = encode_with_intermediate(style, vgg_sd)
+    content_feat = encode(content, vgg_sd)
+    t = adaptive_instance_normalization(content_feat, style_feats[-1])
+    t = alpha * t + (1 - alpha) * content_feat
+    style_re = decoder_forward(style_feats[-1], dec_sd)[:, :1]
+    g_t = decoder_forward(t, dec_sd)
+    g_t_phase, g_t = g_t[:, 1:], g_t[:, :1]
+    g_t_feats = encode_with_intermediate(g_t, vgg_sd)
+    loss_c = _mse(g_t_feats[-1], t)
+    loss_s = 0.0
+    for gf, sf in zip(g_t_feats, style_feats):
+        (gm, gs), (sm, ss) = calc_mean_std(gf), calc_mean_std(sf)
+        loss_s = loss_s + _mse(gm, sm) + _mse(gs, ss)
+    if not field_retrieval:
+        return loss_c, loss_s
+    if unkonwn_distance:
+        d_content = distance_head(*calc_mean_std(content_feat), dist_sd)
+        d_style = distance_head(*calc_mean_std(style_feats[-1]), dist_sd)
+        return loss_c, loss_s, g_t, g_t_phase, style_re, d_content, d_style
+    return loss_c, loss_s, g_t, g_t_phase, style_re
+
+
 def field_retrieval(content, style_vector, vgg_sd, dec_sd, dist_sd=None, alpha=1.0,
                     unkonwn_distance=False):
     """utils/functions.py:22-29 (sic: misspelt keyword)."""

@@ -17,6 +17,7 @@ Outputs (float32 unless noted, all small):
   golden_small.npz       S=32 case with intermediates (encoder stages, stats, AdaIN, decoder)
   golden_edges.npz       B=1, multi-style, alpha 0/0.5, odd size 36, other style vectors
   golden_asm.npz         ASM / Holo_Generator modes on seeded fields (incl. zero_padding=False)
+  golden_forward.npz     Net.forward (the training objective's forward values: losses, g_t, style reconstruction, distances)
 """
 import argparse
 import os
@@ -220,6 +221,22 @@ def main():
     asm_d.update(c2_in_re=o2.real, c2_in_im=o2.imag, c2_re=r2.real.float(), c2_im=r2.imag.float())
     np.savez_compressed(os.path.join(args.out, "golden_asm.npz"),
                         **{k: v.contiguous().numpy() for k, v in asm_d.items()})
+
+    # ---- 5. Net.forward: the training objective's forward values (net.py:199-226) ----------------------
+    # content / style holograms of the 32x32 case, alpha 1.0 and 0.6; every return form of the method
+    fwd = {}
+    ph_style = synth.synthetic_phase_objects(2, 32, seed=13)
+    with torch.no_grad():
+        style_img = torch.sqrt(model_forward(torch.full_like(ph_style, 0.6), ph_style, torch.tensor([0.2, 0.2]).view(-1, 1, 1, 1))).float()
+        for al, tag in ((1.0, "a1"), (0.6, "a06")):
+            lc, ls, g_t, g_ph, s_re, d_c_pred, d_s_pred = network(content, style_img, al, True, True)
+            fwd.update({f"{tag}_loss_c": lc, f"{tag}_loss_s": ls, f"{tag}_g_t": g_t, f"{tag}_g_t_phase": g_ph,
+                        f"{tag}_style_re": s_re, f"{tag}_d_content": d_c_pred, f"{tag}_d_style": d_s_pred})
+        lc2, ls2 = network(content, style_img)
+        five = network(content, style_img, 1.0, True)
+        fwd.update(plain_loss_c=lc2, plain_loss_s=ls2, five_style_re=five[4], style_img=style_img, content=content)
+    np.savez_compressed(os.path.join(args.out, "golden_forward.npz"),
+                        **{k: v.contiguous().numpy() for k, v in fwd.items()}, seed=args.seed)
 
     for f in sorted(os.listdir(args.out)):
         if f.endswith(".npz"):

@@ -325,3 +325,25 @@ def test_module_plumbing_matches_reference_usage(env, mnist_style):
         a2, p2, _ = network.field_retrieval(x, mnist_style.to(dev), 1.0, True)
         assert float((a2 - a0 - 1.0).abs().max()) < 1e-5 and float((p2 - p0 - 1.0).abs().max()) < 1e-5
         network.decoder[37].bias.data -= 1.0
+
+
+def test_net_forward_values_against_reference_golden(env, golden):
+    """Net.forward (net.py:199-226), forward values: content / style losses, generated amplitude and phase,
+    style reconstruction and both predicted distances against the reference's own outputs, for every return form."""
+    g = golden("golden_forward.npz")
+    dev, network = env["dev"], env["net"]
+    c, s = g["content"].to(dev), g["style_img"].to(dev)
+    for al, tag in ((1.0, "a1"), (0.6, "a06")):
+        out = network(c, s, al, True, True)
+        assert len(out) == 7 and not out[0].requires_grad
+        assert abs(float(out[0]) - float(g[f"{tag}_loss_c"])) < TOL * abs(float(g[f"{tag}_loss_c"]))
+        assert abs(float(out[1]) - float(g[f"{tag}_loss_s"])) < TOL * abs(float(g[f"{tag}_loss_s"]))
+        for got, key in zip(out[2:], ("g_t", "g_t_phase", "style_re", "d_content", "d_style")):
+            assert got.shape == g[f"{tag}_{key}"].shape and rel_err(got.cpu(), g[f"{tag}_{key}"]) < TOL, (tag, key)
+    two = network(c, s)
+    assert len(two) == 2 and abs(float(two[0]) - float(g["plain_loss_c"])) < TOL * float(g["plain_loss_c"])
+    assert abs(float(two[1]) - float(g["plain_loss_s"])) < TOL * float(g["plain_loss_s"])
+    five = network(c, s, 1.0, True)
+    assert len(five) == 5 and rel_err(five[4].cpu(), g["five_style_re"]) < TOL
+    with pytest.raises(AssertionError):
+        network(c, s, 1.5)

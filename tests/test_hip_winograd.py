@@ -146,9 +146,12 @@ def test_auto_picks_winograd_only_for_layers_that_fill_the_chip(dev):
     plan = Plan(list(net.decoder.children()))
     conv = next(s for s in plan.steps if s.kind == "conv")
     big = torch.empty(64, 32, 32, conv.conv.in_channels, device="meta")
-    small = torch.empty(2, 16, 16, conv.conv.in_channels, device="meta")     # 16 blocks: not even split-K reaches half a wave
-    assert plan._use_winograd(conv, big) and not plan._use_winograd(conv, small)
+    small = torch.empty(2, 16, 16, conv.conv.in_channels, device="meta")
+    assert plan._use_winograd(conv, big)
+    assert plan._wino_choice(conv, small) == (True, 8)                   # 512 -> 512: 16 blocks x 8 parts of 4 chunks = half a wave
     assert plan._wino_choice(conv, torch.empty(5, 16, 16, conv.conv.in_channels, device="meta")) == (True, 2)   # split-K instead
+    c256 = next(s for s in plan.steps if s.kind == "conv" and s.conv.in_channels == 256 and s.conv.out_channels == 256)
+    assert not plan._use_winograd(c256, torch.empty(2, 16, 16, 256, device="meta"))   # 8 blocks: no admissible split reaches the threshold
     plan.conv_algo = "direct"
     assert not plan._use_winograd(conv, big)
     plan.conv_algo = "winograd"

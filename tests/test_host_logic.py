@@ -135,8 +135,10 @@ def test_cpu_tensors_fail_loudly():
         ASM(torch.zeros(1, 1, 8, 16, dtype=torch.complex64), 5e-7, 1e-4, 1e-6)
     with pytest.raises(AssertionError):
         field_retrieval(network, x, sv, 1.2)
-    with pytest.raises(NotImplementedError):
-        network(x, x)                              # Net.forward = training graph: out of scope
+    with pytest.raises(RuntimeError, match="ROCm device|HIP kernels only"):
+        network(x, x)                              # Net.forward (loss values): the same HIP-only passes
+    with pytest.raises(AssertionError):
+        network(x, x, 1.5)
 
 
 def test_phase_constant_rounding_chain():

@@ -83,12 +83,12 @@ def cpu_baseline(size, sds, style, sample, seed):
                       f"torch {torch.__version__} CPU"}
 
 
-PMC_PROFILE = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+PMC_PROFILE = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 
 
 def pmc_traffic(batch, size, dtype, distances):
     """HBM bytes (conv: per launch; propagator: per call) from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    over this same command (scripts/collect_pmc.py -> profiles/r02_pmc_traffic.json; FETCH_SIZE doubled per
+    over this same command (scripts/collect_pmc.py -> profiles/r03_pmc_traffic.json; FETCH_SIZE doubled per
     MI355X_MICROARCH.md §HBM).  Counters cannot be read from inside the process, so the numbers are only reported for the
     workload AND the library build they were collected on (the profile stores the library's source hash): anything else
     gives null rather than a stale figure."""

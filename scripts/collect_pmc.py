@@ -10,7 +10,7 @@ and only the LAST step's dispatches are summed (the first ones include weight pa
 Writes profiles/<name>.json with the hash of the library the numbers belong to; bench.py reports
 `roofline.traffic` from that file only while the hash matches the loaded library.
 
-    python scripts/collect_pmc.py --out profiles/r02_pmc_traffic.json [-- bench args]
+    python scripts/collect_pmc.py --out profiles/r03_pmc_traffic.json [-- bench args]
 """
 import argparse
 import csv
@@ -69,8 +69,8 @@ def last_step(rows):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(REPO, "profiles", "r02_pmc_traffic.json"))
-    ap.add_argument("--scratch", default=os.path.join(REPO, "gpurun_out", "pmc_r02"))
+    ap.add_argument("--out", default=os.path.join(REPO, "profiles", "r03_pmc_traffic.json"))
+    ap.add_argument("--scratch", default=os.path.join(REPO, "gpurun_out", "pmc_r03"))
     ap.add_argument("bench_args", nargs="*")
     args = ap.parse_args()
     from style_transfer_based_holographic_imaging_amd import build

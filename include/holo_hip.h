@@ -142,6 +142,11 @@ int holo_linear1_sigmoid_f32(const float* x, const float* w, const float* bias, 
 #define HOLO_ASM_OUT_INTENSITY 1 /* out0 = |H|^2                  (Forward_model.py:39) */
 #define HOLO_ASM_OUT_COMPLEX 2   /* out0 = interleaved complex64   (Forward_model.py:36-37) */
 
+/* The float64 phase constants holo_asm_propagate takes, from float32 distances in the reference's units, with the reference's
+ * rounding chain (utils/Forward_model.py:18: ((d + add) * mul) * 1e-3 in fp32; utils/Angular_Spectrum_Method.py:29: 1j*2*pi*d is
+ * complex64, so the product with 2 pi is an fp32 product, promoted to float64 by the grid): out[i] for i < n from
+ * d[(i % period) * d_stride].  One launch instead of five element-wise ones in front of every propagation. */
+int holo_asm_phase_constants_f32(const float* d, long d_stride, int period, float add, float mul, double* out, int n, void* stream);
 /* bytes of scratch holo_asm_propagate needs (two S x P complex64 slabs per field / output) */
 size_t holo_asm_workspace_bytes(int n_fields, int n_dist, int s, int zero_padding);
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "holo_linear_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_rownorm_relu_f32": (_i, [_p, _p, _i, _i, _f, _p]),
     "holo_linear1_sigmoid_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "holo_asm_phase_constants_f32": (_i, [_p, _l, _i, _f, _f, _p, _i, _p]),
     "holo_asm_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "holo_asm_propagate": (_i, [_p, _p, _i, _l, _l, _p, _p, _i, _l, _l, _p, _i, _i, _i, _i, _d, _d, _f, _p, _z, _p]),
     "holo_unwrap2d_workspace_bytes": (_z, [_i, _i, _i]),

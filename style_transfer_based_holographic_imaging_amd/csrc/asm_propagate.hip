@@ -1337,6 +1337,23 @@ __global__ __launch_bounds__(FusedCfg<P>::THREADS, FusedCfg<P>::WAVES_PER_SIMD) 
     }
 }
 
+// Phase constants c of theta = c * G for float32 distances, with the reference's rounding chain in ONE launch
+// (Forward_model.py:18 + Angular_Spectrum_Method.py:29):
+//   c = double( fl32( fl32(2 pi) * fl32( fl32( fl32(d + add) * mul ) * fl32(1e-3) ) ) )
+// — every step a separately rounded fp32 operation, as the torch element-wise ops they replace (five small aten launches in
+// front of every propagation).  out[i] takes d[(i % period) * stride]: period = batch for a per-sample distance, the number
+// of distances for a sweep.
+__global__ __launch_bounds__(256) void phase_constants_kernel(const float* __restrict__ d, long stride, int period, float add,
+                                                             float mul, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t = __fadd_rn(d[(long)(i % period) * stride], add);
+    t = __fmul_rn(t, mul);
+    t = __fmul_rn(t, 1e-3f);
+    t = __fmul_rn(t, 6.28318530717958647692f);     // fl32(2 pi)
+    out[i] = (double)t;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 struct AsmArgs {
     const float *in0, *in1;
@@ -1673,6 +1690,16 @@ static AsmLayout asm_layout(int n_fields, int n_dist, int s, int zero_padding) {
     l.total = ((l.total + 255) & ~(size_t)255) + (8 + 8 * holo::kTraceRecords) * sizeof(unsigned);
 #endif
     return l;
+}
+
+int holo_asm_phase_constants_f32(const float* d, long d_stride, int period, float add, float mul, double* out, int n, void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(d && out, HOLO_ERR_ARG, "holo_asm_phase_constants_f32: null pointer");
+    HOLO_REQUIRE(n > 0 && period > 0 && d_stride >= 0, HOLO_ERR_ARG, "holo_asm_phase_constants_f32: n=%d period=%d stride=%ld", n, period,
+                 d_stride);
+    hipLaunchKernelGGL(phase_constants_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), d, d_stride, period, add,
+                       mul, out, n);
+    return check_launch("holo_asm_phase_constants_f32");
 }
 
 size_t holo_asm_workspace_bytes(int n_fields, int n_dist, int s, int zero_padding) {

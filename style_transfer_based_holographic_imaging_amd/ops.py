@@ -434,6 +434,20 @@ def phase_constant(d, n_fields: int, device) -> torch.Tensor:
     return torch.full((n_fields,), 2 * math.pi * float(d), dtype=torch.float64, device=device)
 
 
+def phase_constant_from_distance(d: torch.Tensor, add: float, mul: float, n_out: int, period: int) -> torch.Tensor:
+    """The same constants as ``phase_constant(((d + add) * mul) * 1e-3, ...)`` for a float32 ROCm tensor ``d`` of ``period``
+    distances in the reference's units (millimetres after normalisation), in ONE launch with the identical fp32 rounding chain
+    (holo_asm_phase_constants_f32): out[i] = c(d[i % period])."""
+    _req(d)
+    d = d.reshape(-1)
+    assert d.dtype == torch.float32 and d.numel() in (1, period)
+    stride = 0 if d.numel() == 1 else d.stride(0)
+    out = torch.empty(n_out, dtype=torch.float64, device=d.device)
+    _launch("holo_asm_phase_constants_f32", lambda: lib.holo_asm_phase_constants_f32(
+        d.data_ptr(), stride, int(period), float(add), float(mul), out.data_ptr(), int(n_out), _stream()))
+    return out
+
+
 def _field_stride(t: torch.Tensor, s: int):
     """Element stride between consecutive (b,c) fields of a (B,C,S,S) tensor whose planes are
     contiguous, or None when the fields are not evenly spaced."""

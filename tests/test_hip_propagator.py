@@ -309,3 +309,33 @@ def test_dataflow_variant_stays_parity_green(b, s, dist):
     c = re.search(r"ctl: next_field (\d+) error (\d+) .* local fields/XCD \[([-0-9, ]+)\]", r.stdout)
     assert c and int(c.group(2)) == 0, r.stdout
     assert sum(max(0, int(v)) for v in c.group(3).split(",")) == b          # every field claimed by exactly one XCD
+
+
+def test_phase_constants_kernel_reproduces_the_aten_rounding_chain(hg, dev):
+    """holo_asm_phase_constants_f32 against the element-wise torch chain it replaces (Forward_model.py:18 then
+    Angular_Spectrum_Method.py:29): bit-identical float64 constants for random distances, offsets and scales, per-sample,
+    broadcast and sweep (period) forms — and the propagation through Holo_Generator is unchanged by it."""
+    from style_transfer_based_holographic_imaging_amd import ops
+    import types
+    g = torch.Generator().manual_seed(17)
+    for add, mul in ((0.0, 1.0), (0.137, 2.5), (-0.05, 0.731)):
+        d = ((torch.rand(37, generator=g) - 0.5) * 3.0).to(dev)
+        want = ops.phase_constant(((d + add) * mul) * 1e-3, 37, dev)
+        got = ops.phase_constant_from_distance(d, add, mul, 37, 37)
+        assert got.dtype == torch.float64 and torch.equal(got, want)
+        sweep = ops.phase_constant_from_distance(d[:8].contiguous(), add, mul, 5 * 8, 8)
+        assert torch.equal(sweep, want[:8].repeat(5))
+        one = ops.phase_constant_from_distance(d[3:4], add, mul, 6, 6)
+        assert torch.equal(one, want[3:4].expand(6))
+    hp = types.SimpleNamespace(wavelength=532e-9, pixel_size=1.5e-6, distance_normalize=0.8, distance_normalize_constant=0.05, phase_normalize=1.0)
+    from utils.Forward_model import Holo_Generator
+    gen = Holo_Generator(hp)
+    amp, ph = (torch.rand(3, 1, 64, 64, generator=g) + 0.3).to(dev), torch.rand(3, 1, 64, 64, generator=g).to(dev)
+    d3 = torch.tensor([0.4, -0.2, 0.7]).view(-1, 1, 1, 1).to(dev)
+    fast = gen(amp, ph, d3, return_field=True)
+    pc = ops.phase_constant(((d3 + 0.05) * 0.8) * 1e-3, 3, dev)                      # the torch chain, fed to the low-level launcher
+    from style_transfer_based_holographic_imaging_amd import _lib
+    ref = ops.asm_propagate(amp, ph, pc, 64, True, 532e-9, 1.5e-6, 1.0, _lib.ASM_OUT_AMP_PHASE)
+    assert torch.equal(fast[0], ref[0]) and torch.equal(fast[1], ref[1])
+    slow = gen(amp, ph, d3.double(), return_field=True)        # a float64 tensor takes the torch path (float64 chain: other bits, same field)
+    assert float((fast[0] - slow[0]).abs().max()) < 1e-4

@@ -38,12 +38,16 @@ class Holo_Generator(nn.Module):
         b, c, s, s2 = amplitude.shape
         if s != s2:
             raise RuntimeError(f"amplitude {tuple(amplitude.shape)} / phase {tuple(phase.shape)} must be square")
-        d = self._distance_m(d)
-        if isinstance(d, torch.Tensor) and d.numel() > 1:
-            if d.numel() != b:
-                raise RuntimeError(f"distance tensor of {d.numel()} entries does not match batch {b}")
-            d = d.reshape(b, 1).expand(b, c).reshape(-1)
-        phase_c = ops.phase_constant(d, b * c, amplitude.device)
+        if isinstance(d, torch.Tensor) and d.is_cuda and d.dtype == torch.float32 and c == 1 and d.numel() in (1, b):
+            # the usual call: per-sample float32 distances on the device -> one launch with the reference's rounding chain
+            phase_c = ops.phase_constant_from_distance(d, self.distance_normalize_constant, self.distance_normalize, b, b)
+        else:
+            d = self._distance_m(d)
+            if isinstance(d, torch.Tensor) and d.numel() > 1:
+                if d.numel() != b:
+                    raise RuntimeError(f"distance tensor of {d.numel()} entries does not match batch {b}")
+                d = d.reshape(b, 1).expand(b, c).reshape(-1)
+            phase_c = ops.phase_constant(d, b * c, amplitude.device)
         mode = (_lib.ASM_OUT_AMP_PHASE if return_field else
                 _lib.ASM_OUT_COMPLEX if complex_number else _lib.ASM_OUT_INTENSITY)
         out0, out1 = ops.asm_propagate(amplitude, phase, phase_c, s, True, self.wavelength, self.pixel_size,
@@ -64,8 +68,7 @@ class Holo_Generator(nn.Module):
             raise RuntimeError("sweep expects single-channel fields")
         dist = torch.as_tensor(distances, dtype=torch.float32, device=amplitude.device).reshape(-1)
         n = dist.numel()
-        d = self._distance_m(dist).reshape(1, n).expand(b, n).reshape(-1)
-        phase_c = ops.phase_constant(d, b * n, amplitude.device)
+        phase_c = ops.phase_constant_from_distance(dist, self.distance_normalize_constant, self.distance_normalize, b * n, n)
         mode = _lib.ASM_OUT_AMP_PHASE if return_field else _lib.ASM_OUT_INTENSITY
         out0, out1 = ops.asm_propagate(amplitude, phase, phase_c, s, True, self.wavelength, self.pixel_size,
                                        self.phase_normalize, mode, n_dist=n)

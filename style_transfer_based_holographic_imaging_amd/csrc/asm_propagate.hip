@@ -43,6 +43,16 @@ namespace holo {
 
 constexpr int kRowThreads = 256;
 
+// timing experiments of the row kernels (-DHOLO_DEBUG builds only, HOLO_ASM_ABLATE=<bits>; wrong results): K1: 4 no sincos,
+// 8 no FFT, 16 no transposed store, 32 no input loads; K3: 64 no loads, 128 no FFT, 256 no abs/angle, 512 no stores.
+// In the shipped build ASM_ABL() is the constant 0 and leaves no code behind.
+#ifdef HOLO_DEBUG
+__device__ int g_asm_abl = 0;
+#define ASM_ABL(bit_) (g_asm_abl & (bit_))
+#else
+#define ASM_ABL(bit_) 0
+#endif
+
 // workspace head: tables of the generic-size path (twiddles W_P^m and squared frequencies, P <= 4096); the
 // power-of-two kernels build their twiddles in LDS themselves and need no table
 constexpr int kTwSlots = 4096;
@@ -486,6 +496,12 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
 // ================================================================================================================
 // Transposed-intermediate kernels (32 <= P <= 1024, S a multiple of 16): T and U are [field][kx][y].
 // ================================================================================================================
+#ifndef HOLO_ASM_ABL_CONTIG
+#define HOLO_ASM_ABL_CONTIG 0
+#endif
+#ifndef HOLO_ASM_PERSIST_FWD
+#define HOLO_ASM_PERSIST_FWD 1   // forward row kernel of the transposed path: persistent blocks that prefetch the next tile's raw inputs
+#endif
 #ifndef HOLO_ASM_PERSIST_ROWS
 #define HOLO_ASM_PERSIST_ROWS 1   // inverse row kernel of the transposed path at P >= 1024: persistent blocks that prefetch the next tile
 #endif
@@ -539,7 +555,7 @@ template <int P, bool PAD>
 __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_entries_fwd<P>())) void asm_rows_fwd_t_kernel(
     const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
     float phase_scale, v2f* __restrict__ tbuf, int tab_blocks, v2f* __restrict__ htab,
-    const double* __restrict__ phase_const, int n_out, double inv_ppx, double lam2, double lamb) {
+    const double* __restrict__ phase_const, int n_out, double inv_ppx, double lam2, double lamb, int n_row_tiles) {
     using C = RowTCfg<P>;
     if ((int)blockIdx.x < tab_blocks) {
         // table blocks (dispatched FIRST, so that they run beside the row blocks instead of forming a tail): block j computes
@@ -582,24 +598,30 @@ __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_
 
     const int tid = threadIdx.x;
     const int seq = tid / G, t = tid % G;
-    const long row0 = (long)((int)blockIdx.x - tab_blocks) * kTileRows;
-    const long f = row0 / S;
-    const int y0 = (int)(row0 % S);
     v2f* my = buf + seq * PITCH;
-    fft_fill_twiddles<P, -1>(tw, tid, THREADS);
 
-    v2f v[E];
-    {
-        const int y = y0 + seq;
+    // PERSISTENT over 16-row tiles (round 3): a block keeps its twiddle table and, before it transforms a tile, requests the
+    // RAW inputs of its next one (amplitude / phase or re / im: E interior values + two edges per lane) into registers.
+    // Ablation (HOLO_ASM_ABLATE, 64 x 256^2): of this kernel's 26 us, 14.5 vanish with the input loads and 16 with the
+    // transposing store although each moves its bytes in ~3 and ~10 us — one-tile blocks wait out the full load latency at
+    // their start, two lockstep blocks per CU, two rounds.
+    // element index i = j + r*P/R1 with j < P/R1: the replicate-pad regions (Angular_Spectrum_Method.py:12) are whole
+    // r-slices.  The two edge values (columns 0 and S-1) are interior elements of the row's first / last lane where the
+    // row is one butterfly per lane (broadcast instead of loaded).
+    constexpr bool ONE_BFLY = (E == R1) && (G <= 64);
+    constexpr int NRAW = E + 2;                      // raw slots: interior elements at their e, edges at E, E + 1
+    auto load_raw = [&](int tile, v2f (&raw)[NRAW]) {
+        const long row0 = (long)tile * kTileRows;
+        const long f = row0 / S;
+        const int y = (int)(row0 % S) + seq;
         const long base0 = f * stride0 + (long)y * S, base1 = f * stride1 + (long)y * S;
-        // element index i = j + r*P/R1 with j < P/R1: the replicate-pad regions (Angular_Spectrum_Method.py:12) are
-        // whole r-slices.  Interior elements are loaded and packed first; the two edge values (columns 0 and S-1)
-        // are interior elements of the row's first / last lane, so they are broadcast instead of recomputed.
-        constexpr bool ONE_BFLY = (E == R1) && (G <= 64);
-        v2f edge0 = {0.f, 0.f}, edge1 = edge0;
+        auto fetch = [&](long col) {
+            if (in_mode == HOLO_ASM_IN_COMPLEX) return reinterpret_cast<const v2f*>(in0)[base0 + col];
+            return v2f{in0[base0 + col], in1[base1 + col]};
+        };
         if (PAD && !ONE_BFLY) {
-            edge0 = load_field(in0, in1, in_mode, base0, base1, phase_scale);
-            edge1 = load_field(in0, in1, in_mode, base0 + S - 1, base1 + S - 1, phase_scale);
+            raw[E] = fetch(0);
+            raw[E + 1] = fetch(S - 1);
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -608,34 +630,72 @@ __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_
             const bool right = PAD && r * 4 >= 3 * R1;
             if (!left && !right) {
                 const int i = fft_elem_index<P, G, R1>(t, e);
-                const int col = PAD ? i - S / 2 : i;
-                v[e] = load_field(in0, in1, in_mode, base0 + col, base1 + col, phase_scale);
+                raw[e] = ASM_ABL(32) ? v2f{(float)tid, (float)e} : fetch(PAD ? i - S / 2 : i);
             }
         }
-        if (PAD && ONE_BFLY) {
-            const v2f lo = v[R1 / 4], hi = v[3 * R1 / 4 - 1];
-            edge0 = v2f{__shfl(lo.x, 0, G), __shfl(lo.y, 0, G)};
-            edge1 = v2f{__shfl(hi.x, G - 1, G), __shfl(hi.y, G - 1, G)};
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int r = e % R1;
-            if (PAD && (r + 1) * 4 <= R1) v[e] = edge0;
-            if (PAD && r * 4 >= 3 * R1) v[e] = edge1;
-        }
-    }
+    };
+    // Forward_model.py:20-22: phase*phase_normalize, then amplitude*exp(1j*phase) in complex64
+    auto pack = [&](v2f r) {
+        if (in_mode == HOLO_ASM_IN_COMPLEX || ASM_ABL(4)) return r;
+        float sn, cs;
+        sincos_f32(r.y * phase_scale, &sn, &cs);
+        return v2f{r.x * cs, r.x * sn};
+    };
+    const int n_tiles = (int)gridDim.x - tab_blocks >= 0 ? n_row_tiles : 0;
+    int tile = (int)blockIdx.x - tab_blocks;
+    const int stride_t = (int)gridDim.x - tab_blocks;
+    v2f raw[NRAW];
+    if (tile < n_tiles) load_raw(tile, raw);
+    fft_fill_twiddles<P, -1>(tw, tid, THREADS);   // behind the first tile's loads
     __syncthreads();  // twiddle table
-    fft_run<P, G, -1>(v, my, tw, t);
-    __syncthreads();  // every row is done with its FFT buffer: the tile aliases them
+    for (; tile < n_tiles; tile += stride_t) {
+        v2f v[E];
+        {
+            v2f edge0 = {0.f, 0.f}, edge1 = edge0;
+            if (PAD && !ONE_BFLY) {
+                edge0 = pack(raw[E]);
+                edge1 = pack(raw[E + 1]);
+            }
 #pragma unroll
-    for (int e = 0; e < E; ++e) buf[fft_elem_index<P, G, RL>(t, e) * kTilePitch + seq] = v[e];
-    __syncthreads();
-    // T^T[f][kx][y0 .. y0+15]: one 128-B run per kx, 16 B per thread
-    v2f* dst = tbuf + ((long)f * P) * S + y0;
-    for (int q = tid; q < P * (kTileRows / 2); q += THREADS) {
-        const int kx = q / (kTileRows / 2), j = q % (kTileRows / 2);
-        const v2f a = buf[kx * kTilePitch + 2 * j], b = buf[kx * kTilePitch + 2 * j + 1];
-        *reinterpret_cast<float4*>(dst + (long)kx * S + 2 * j) = make_float4(a.x, a.y, b.x, b.y);
+            for (int e = 0; e < E; ++e) {
+                const int r = e % R1;
+                const bool left = PAD && (r + 1) * 4 <= R1;
+                const bool right = PAD && r * 4 >= 3 * R1;
+                if (!left && !right) v[e] = pack(raw[e]);
+            }
+            if (PAD && ONE_BFLY) {
+                const v2f lo = v[R1 / 4], hi = v[3 * R1 / 4 - 1];
+                edge0 = v2f{__shfl(lo.x, 0, G), __shfl(lo.y, 0, G)};
+                edge1 = v2f{__shfl(hi.x, G - 1, G), __shfl(hi.y, G - 1, G)};
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int r = e % R1;
+                if (PAD && (r + 1) * 4 <= R1) v[e] = edge0;
+                if (PAD && r * 4 >= 3 * R1) v[e] = edge1;
+            }
+        }
+        if (tile + stride_t < n_tiles) load_raw(tile + stride_t, raw);   // in flight during this tile's transform and store
+        const long row0 = (long)tile * kTileRows;
+        const long f = row0 / S;
+        const int y0 = (int)(row0 % S);
+        if (!ASM_ABL(8)) fft_run<P, G, -1>(v, my, tw, t);
+        if (ASM_ABL(16)) {
+            if (tid == 0) tbuf[((long)f * P) * S + y0] = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7];
+            continue;
+        }
+        __syncthreads();  // every row is done with its FFT buffer: the tile aliases them
+#pragma unroll
+        for (int e = 0; e < E; ++e) buf[fft_elem_index<P, G, RL>(t, e) * kTilePitch + seq] = v[e];
+        __syncthreads();
+        // T^T[f][kx][y0 .. y0+15]: one 128-B run per kx, 16 B per thread
+        v2f* dst = tbuf + ((long)f * P) * S + y0;
+        for (int q = tid; q < P * (kTileRows / 2); q += THREADS) {
+            const int kx = q / (kTileRows / 2), j = q % (kTileRows / 2);
+            const v2f a = buf[kx * kTilePitch + 2 * j], b = buf[kx * kTilePitch + 2 * j + 1];
+            *reinterpret_cast<float4*>(dst + (long)kx * S + 2 * j) = make_float4(a.x, a.y, b.x, b.y);
+        }
+        __syncthreads();  // the tile is read out: the next transform writes the FFT buffers it aliases
     }
 }
 
@@ -781,10 +841,18 @@ __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_
     auto load_tile = [&](int tile, float4 (&pre)[LD]) {
         const long row0 = (long)tile * kTileRows;
         const v2f* src = ubuf + (row0 / S) * P * S + (row0 % S);
+#if HOLO_ASM_ABL_CONTIG
+        src = ubuf + (row0 / S) * P * S + ((row0 % S) / kTileRows) * (long)(P * kTileRows);
+#endif
 #pragma unroll
         for (int l = 0; l < LD; ++l) {
             const int q = tid + l * THREADS;
-            pre[l] = *reinterpret_cast<const float4*>(src + (long)(q / (kTileRows / 2)) * S + 2 * (q % (kTileRows / 2)));
+#if HOLO_ASM_ABL_CONTIG
+            pre[l] = *reinterpret_cast<const float4*>(src + (long)q * 2);
+#else
+            if (ASM_ABL(64)) pre[l] = make_float4((float)q, 1.f, 2.f, 3.f);
+            else pre[l] = *reinterpret_cast<const float4*>(src + (long)(q / (kTileRows / 2)) * S + 2 * (q % (kTileRows / 2)));
+#endif
         }
     };
     float4 pre[LD];
@@ -805,7 +873,7 @@ __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_
         for (int e = 0; e < E; ++e) v[e] = buf[fft_elem_index<P, G, R1>(t, e) * kTilePitch + seq];
         __syncthreads();  // the tile is consumed: its space becomes the rows' FFT buffers
         if (tile + (int)gridDim.x < n_tiles) load_tile(tile + gridDim.x, pre);
-        fft_run<P, G, +1>(v, my, tw, t);
+        if (!ASM_ABL(128)) fft_run<P, G, +1>(v, my, tw, t);
         {
             const long row0 = (long)tile * kTileRows;
             const long fo = row0 / S;
@@ -819,7 +887,12 @@ __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_
                 const int x = PAD ? i - S / 2 : i;
                 const v2f o = v[e] * scale;
                 const long pix = (long)y * S + x;
-                if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
+                if (ASM_ABL(512)) {
+                    if (o.x == 12345.678f) out0[pix] = o.y;
+                } else if (ASM_ABL(256)) {
+                    out0[fo * ostride0 + pix] = o.x;
+                    out1[fo * ostride1 + pix] = o.y;
+                } else if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
                     out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
                     out1[fo * ostride1 + pix] = atan2_poly(o.y, o.x);
                 } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
@@ -1453,9 +1526,13 @@ static int launch_asm_t(const AsmArgs& a) {
     const int slots = n_out < kHSlots ? n_out : kHSlots;
     const long tab_blocks = tables ? (long)((htab_elems<P>() + R::THREADS - 1) / R::THREADS) : 0;
     (void)slots;
-    hipLaunchKernelGGL((asm_rows_fwd_t_kernel<P, PAD>), dim3((unsigned)(blocks_in + tab_blocks)), dim3(R::THREADS), row_lds_f,
+    // persistent row blocks: as many as are resident at once (LDS / wave limit), each walking tiles with that stride
+    const long fwd_slots = (long)device_cus() * R::bpc(tw_entries_fwd<P>());
+    const long fwd_grid = (HOLO_ASM_PERSIST_FWD && blocks_in > fwd_slots) ? fwd_slots : blocks_in;
+    hipLaunchKernelGGL((asm_rows_fwd_t_kernel<P, PAD>), dim3((unsigned)(fwd_grid + tab_blocks)), dim3(R::THREADS), row_lds_f,
                        a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf),
-                       (int)tab_blocks, reinterpret_cast<v2f*>(a.htab), a.phase_const, n_out, 1.0 / a.ppx, a.lam2, a.lamb);
+                       (int)tab_blocks, reinterpret_cast<v2f*>(a.htab), a.phase_const, n_out, 1.0 / a.ppx, a.lam2, a.lamb,
+                       (int)blocks_in);
     hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD>), dim3(P / C::CW, n_out), dim3(C::THREADS), C::LDS, a.stream,
                        reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
                        1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr);
@@ -1771,7 +1848,13 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
 #ifdef HOLO_DEBUG   // timing experiments only (wrong results): never read in the shipped build
     {
         const char* env = getenv("HOLO_ASM_ABLATE");
-        a.ablate = env ? atoi(env) : 0;
+        const int bits = env ? atoi(env) : 0;
+        a.ablate = bits & 3;
+        static int last = -1;
+        if (bits != last) {
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(holo::g_asm_abl), &bits, sizeof(int));
+            last = bits;
+        }
     }
 #endif
     const bool pad = zero_padding != 0;

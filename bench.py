@@ -175,16 +175,14 @@ def main():
         # config 4: hologram i of the job is a function of i alone (chunks of 64 seeded 1236 + chunk), whatever the rank count
         lo, hi = shard.shard_bounds(args.total, world, rank)
         seed = 1236
+        ph_j, d_j = synth.job_inputs(lo, hi, s, seed=seed)
         chunks = []
-        for c in range(lo // 64, (max(hi, lo + 1) - 1) // 64 + 1):
-            c_lo = max(lo, 64 * c) - 64 * c
-            c_hi = min(hi, 64 * c + 64) - 64 * c
-            ph_c = synth.synthetic_phase_objects(64, s, seed=seed + c)[c_lo:c_hi].to(dev)
-            d_c = synth.synthetic_distances(64, seed=seed + c)[c_lo:c_hi].to(dev)
+        for c0 in range(0, hi - lo, 64):        # forward propagation in pieces of 64 (the generator's own chunking is index-based)
+            ph_c, d_c = ph_j[c0:c0 + 64].to(dev), d_j[c0:c0 + 64].to(dev)
             with torch.no_grad():
                 chunks.append(torch.sqrt(model_forward(torch.full_like(ph_c, 0.6), ph_c, d_c)))
         content = torch.cat(chunks, 0).contiguous() if chunks else torch.empty((0, 1, s, s), device=dev)
-        del chunks
+        del chunks, ph_j, d_j
         n_local = hi - lo
         d_style = torch.full((max(b, 1), 1, 1, 1), -0.2, device=dev)     # back-propagation: -distance_style (test_field_retrieval_mnist.py:126)
         block = torch.empty((n_local, shard.packed_width(s)), dtype=torch.float32, device=dev)

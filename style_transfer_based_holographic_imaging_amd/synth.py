@@ -113,6 +113,21 @@ def synthetic_distances(batch: int, seed: int = 1234):
     return torch.from_numpy(d.astype(np.float32)).view(-1, 1, 1, 1)
 
 
+def job_inputs(lo: int, hi: int, size: int, seed: int = 1236, chunk: int = 64):
+    """Phase objects and content distances of holograms [lo, hi) of a fixed-total job (BASELINE configs[3]): hologram i is
+    a function of i ALONE — chunk i // chunk is drawn from seed + chunk index — so any sharding of the job over ranks gives
+    the same holograms.  Returns ((hi-lo,1,S,S) phase objects, (hi-lo,1,1,1) distances in mm)."""
+    phs, ds = [], []
+    if hi > lo:
+        for c in range(lo // chunk, (hi - 1) // chunk + 1):
+            c_lo, c_hi = max(lo, chunk * c) - chunk * c, min(hi, chunk * c + chunk) - chunk * c
+            phs.append(synthetic_phase_objects(chunk, size, seed=seed + c)[c_lo:c_hi])
+            ds.append(synthetic_distances(chunk, seed=seed + c)[c_lo:c_hi])
+    if not phs:
+        return torch.zeros((0, 1, size, size)), torch.zeros((0, 1, 1, 1))
+    return torch.cat(phs, 0), torch.cat(ds, 0)
+
+
 class SyntheticDigits(torch.utils.data.Dataset):
     """Stand-in for ``torchvision.datasets.MNIST`` (absent offline): ``n`` seeded 28 x 28 digit-like blobs in [0, 1] with a
     label, indexable like the dataset ``utils.Data_loader.mnist_loader(_test)`` draws its first shuffled batch from."""

@@ -30,7 +30,7 @@ d_c = synth.synthetic_distances(n, seed=4321)
 with torch.no_grad():
     content = torch.sqrt(orc.holo_generator(hp, torch.full_like(ph, 0.6), ph, d_c)).float()
     ref = orc.net_field_retrieval(content, style, *sds, 1.0, True)
-    for algo in ("direct", "winograd"):
+    for algo in ("direct", "winograd", "auto"):      # "auto" at small n includes the split-K Winograd layers
         network.set_conv_algo(algo)
         got = field_retrieval(network, content.to(DEV), style.to(DEV), 1.0, True)
         for i, name in enumerate(("amplitude", "phase")):

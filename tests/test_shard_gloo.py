@@ -146,3 +146,18 @@ def test_two_rank_strong_scaling_pass(tmp_path, n_total, micro):
     for k, t in enumerate((amp, ph, a_f, p_f)):
         assert torch.equal(t, idx * 1000 + base + k)
     assert torch.allclose(d, idx * 0.001)
+
+
+def test_job_inputs_do_not_depend_on_the_sharding():
+    """bench.py --total: hologram i of the job is a function of i alone, whatever the number of ranks."""
+    from style_transfer_based_holographic_imaging_amd import synth
+    from style_transfer_based_holographic_imaging_amd.shard import shard_bounds
+    n, size = 150, 96
+    whole_p, whole_d = synth.job_inputs(0, n, size)
+    assert whole_p.shape == (n, 1, size, size) and whole_d.shape == (n, 1, 1, 1)
+    for world in (2, 3, 8):
+        parts = [synth.job_inputs(*shard_bounds(n, world, r), size) for r in range(world)]
+        assert torch.equal(torch.cat([p for p, _ in parts], 0), whole_p)
+        assert torch.equal(torch.cat([d for _, d in parts], 0), whole_d)
+    empty_p, empty_d = synth.job_inputs(5, 5, size)
+    assert empty_p.shape == (0, 1, size, size) and empty_d.shape == (0, 1, 1, 1)

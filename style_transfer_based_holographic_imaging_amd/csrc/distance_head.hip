@@ -24,7 +24,13 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
         for (int i = 0; i < kBT; ++i) {
             const int b = b0 + i < batch ? b0 + i : batch - 1;
             const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)b * k + kk);
-            acc[i] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+            // one explicit FMA chain per sample slot: with `acc += x.x*w.x + x.y*w.y + ...` hipcc contracted and paired the eight
+            // slots differently, and a sample's result depended (by an ulp) on its position in the batch (found in round 3 by
+            // comparing a sharded pass with the unsharded batch)
+            acc[i] = fmaf(xv.x, wv.x, acc[i]);
+            acc[i] = fmaf(xv.y, wv.y, acc[i]);
+            acc[i] = fmaf(xv.z, wv.z, acc[i]);
+            acc[i] = fmaf(xv.w, wv.w, acc[i]);
         }
     }
 #pragma unroll

@@ -150,3 +150,18 @@ def test_errors_are_loud(ops, dev):
         ops.conv3x3(x, torch.zeros(9 * 16 * 64, device=dev), torch.zeros(64, device=dev), 64)
     with pytest.raises(RuntimeError, match="multiple of 16"):
         ops.conv3x3(torch.zeros(1, 4, 4, 24, device=dev), torch.zeros(9 * 24 * 64, device=dev), torch.zeros(64, device=dev), 64)
+
+
+def test_distance_head_does_not_depend_on_the_position_in_the_batch():
+    """A sample's distance is bit-identical wherever it sits in a batch (shards of a multi-GPU job start at arbitrary
+    offsets; the linear kernel handles eight samples per wave and each slot must run the same arithmetic)."""
+    from hip_helpers import DEV, build_network
+    from style_transfer_based_holographic_imaging_amd import ops
+    _, sds = build_network(0)
+    sd = {k: v.to(DEV) for k, v in sds[2].items()}
+    g = torch.Generator().manual_seed(0)
+    mean, std = torch.randn(40, 512, generator=g).to(DEV), (torch.rand(40, 512, generator=g) + 0.1).to(DEV)
+    whole = ops.distance_head(mean, std, sd)
+    for lo, hi in ((0, 7), (4, 11), (8, 16), (20, 40), (33, 40), (39, 40)):
+        part = ops.distance_head(mean[lo:hi].contiguous(), std[lo:hi].contiguous(), sd)
+        assert torch.equal(part, whole[lo:hi]), (lo, hi)

@@ -347,3 +347,33 @@ def test_net_forward_values_against_reference_golden(env, golden):
     assert len(five) == 5 and rel_err(five[4].cpu(), g["five_style_re"]) < TOL
     with pytest.raises(AssertionError):
         network(c, s, 1.5)
+
+
+def test_fixed_total_pass_equals_one_batch(env, mnist_style):
+    """bench.py --total on one rank (shard.sharded_pass): 40 holograms walked in micro-batches of at most 24 (near-equal
+    pieces of 20 / 20 — the batch bucket of 16 and more, hence the kernel selection of the whole batch) and packed block by
+    block give, bit for bit, what one 40-hologram batch gives; unpack_outputs returns the five tensors."""
+    from style_transfer_based_holographic_imaging_amd import shard, synth
+    from utils.functions import field_retrieval
+    dev, network, hg = env["dev"], env["net"], env["hg"]
+    ph, d_c = synth.job_inputs(0, 40, 64)
+    sv = mnist_style.to(dev)
+    d_s = torch.full((40, 1, 1, 1), -0.2, device=dev)
+    with torch.no_grad():
+        content = torch.sqrt(hg(torch.full_like(ph, 0.6).to(dev), ph.to(dev), d_c.to(dev)))
+
+        def one(x, d):
+            amp, p, dist = field_retrieval(network, x, sv, 1.0, True)
+            a_f, p_f = hg(amp, p, d, return_field=True)
+            return amp, p, a_f, p_f, dist
+        pieces = []
+
+        def process(m0, m1, rows):
+            pieces.append((m0, m1))
+            shard.pack_outputs(*one(content[m0:m1], d_s[m0:m1]), out=rows)
+        packed = shard.sharded_pass(40, 24, process, shard.packed_width(64), dev)
+        whole = one(content, d_s)
+    assert [b - a for a, b in pieces] == [20, 20] and packed.shape == (40, 4 * 64 * 64 + 1)
+    got = shard.unpack_outputs(packed, 64)
+    for g, w in zip(got, whole):
+        assert torch.equal(g, w.reshape(g.shape))

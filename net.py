@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from function import calc_mean_std
 from style_transfer_based_holographic_imaging_amd import ops
+from style_transfer_based_holographic_imaging_amd import torch_ops  # noqa: F401  (registers the holo:: operators with the dispatcher)
 from style_transfer_based_holographic_imaging_amd.engine import HoloSequential
 
 

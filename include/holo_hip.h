@@ -86,7 +86,7 @@ int holo_conv3x3_wino_f32(const float* x_nhwc, const float* w_packed, const floa
                           int batch, int h, int w, int cin, int cout, int relu, int pool, void* stream);
 /* The same layer for launches too small to fill the chip (small batches, the deep low-resolution layers: the bundled
  * 5 x 128^2 case has 80 tiles for 256 CUs): split-K.  The Cin/16 channel chunks of every tile are dealt to `ksplit` work items
- * (ksplit in [2,8], dividing Cin/16 into parts of at least 2 chunks); each writes raw partial sums into `workspace`
+ * (ksplit in [2,8]; item s sums chunks [s*n/ksplit, (s+1)*n/ksplit) of the n = Cin/16, every part at least 2); each writes raw partial sums into `workspace`
  * (holo_conv3x3_wino_splitk_workspace_bytes = ksplit * B*H*W*Cout floats) and a second launch adds the partials in the fixed
  * order 0, 1, ... with bias, ReLU and pooling — deterministic and independent of the batch a hologram arrives in.  Differs from
  * holo_conv3x3_wino_f32 by fp32 rounding (the summation over channels is re-associated). */

@@ -18,7 +18,10 @@ if not hasattr(lib, "holo_wino_debug_read"):
     raise SystemExit("this library was not built with -DWINO_STAMPS=1")
 dev = torch.device("cuda:0")
 names = ["step0", "sync0", "step1", "sync1", "loop top (+plan)", "epilogue", "zero+switch"]
-for b, c, hw in ((64, 64, 256), (64, 256, 64), (64, 512, 32)):
+shapes = ((64, 64, 256), (64, 256, 64), (64, 512, 32))
+if len(sys.argv) > 1:     # e.g. 5,256,32 5,512,16  (batch, channels, side)
+    shapes = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[1:])
+for b, c, hw in shapes:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(b, c, hw, hw, generator=g)
     wt = torch.randn(c, c, 3, 3, generator=g) * math.sqrt(2 / (9 * c))

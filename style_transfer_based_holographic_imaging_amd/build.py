@@ -112,6 +112,7 @@ def _lock_path(out):
 def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = OUT):
     """Build (if stale) and return the library path.  `extra_flags` / `out` make side builds
     (-DHOLO_DEBUG ablation knobs, -DHOLO_CONV_STAMPS=1) that never replace the shipped library."""
+    out = os.path.abspath(out)                          # hipcc runs with csrc/ as its working directory
     want = source_hash(extra_flags)
     if not force and built_hash(out) == want and built_rocm_version(out) == _rocm_version():
         return out                                      # up to date: no lock file is touched (read-only installs)

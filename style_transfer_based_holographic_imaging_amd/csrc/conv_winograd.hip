@@ -115,7 +115,8 @@ __device__ __forceinline__ int slot_of(int hy, int hx) { return hy * kHW + (hx &
     }
 
 // ksplit > 1 (split-K, for launches that would leave most CUs idle): a tile's channel chunks are dealt to `ksplit` work
-// items, each summing nchunks / ksplit of them; item s writes its RAW partial outputs (no bias, no activation) to
+// items, item s summing chunks [s*n/ksplit .. (s+1)*n/ksplit) (parts differ by at most one chunk: ksplit need not divide
+// n, so that items * ksplit can be matched to the CU count); item s writes its RAW partial outputs (no bias, no activation) to
 // y + s * part_stride, and holo_splitk_reduce_f32 adds the partials in the fixed order s = 0, 1, ... with bias, ReLU and
 // pooling.  The split index is one more dimension of the persistent tile id: the loop body is unchanged.
 __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
@@ -130,7 +131,6 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     const int lane = tid & 63, wave = tid >> 6;
     const int n_blk = Cout / kTN;
     const int nchunks_all = Cin / 16;            // chunks of the layer (stride of the packed weights)
-    const int nchunks = nchunks_all / ksplit;    // chunks one work item sums (the entry point checks divisibility)
 
     // ---- tiles ----------------------------------------------------------------------------------------------------
     // The grid is PERSISTENT: block b works on tiles b, b + gridDim.x, ... (one block per CU: 512 registers per lane).  A
@@ -138,21 +138,26 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     // launch — were ~10 us against 14 us of MFMA work for the 64-channel layers; here the next tile's first chunk is
     // requested during the current tile's last chunk and the first MFMA of a tile takes C = 0.
     // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): XCD c gets a contiguous range of tile ids, so that
-    // the channel blocks of one patch (same halo) and neighbouring patches meet in one L2 at about the same time.
+    // the channel blocks of one patch (same halo, same weights) meet in one L2 at about the same time.
     // Bijective when the tile count is a multiple of 8; speed only.
-    struct Tile { int nb, img, y0, x0, ks; };
+    const int batch = total / (ksplit * n_blk * tiles_x * tiles_y);
+    struct Tile { int nb, img, y0, x0, ks, c0, nc; };   // c0, nc: first chunk and number of chunks of this work item
     auto decode = [&](int vb) {
         int bid = vb;
         if ((total & 7) == 0) bid = (vb & 7) * (total >> 3) + (vb >> 3);
         Tile t;
         t.ks = bid % ksplit;                     // fastest: the work items of one tile share its halo in one L2
         bid /= ksplit;
+        t.c0 = t.ks * nchunks_all / ksplit;
+        t.nc = (t.ks + 1) * nchunks_all / ksplit - t.c0;
         t.nb = bid % n_blk;
         bid /= n_blk;
+        // images before positions: a block's consecutive tiles (ids 32 apart within its XCD's range) then sit at the SAME
+        // position of different images, and the staging plan — a function of (y0, x0) only — is kept (+0.3 % at batch 64)
+        t.img = bid % batch;
+        bid /= batch;
         t.x0 = (bid % tiles_x) * kPW;
-        bid /= tiles_x;
-        t.y0 = (bid % tiles_y) * kPH;
-        t.img = bid / tiles_y;
+        t.y0 = (bid / tiles_x) * kPH;
         return t;
     };
 
@@ -417,8 +422,8 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     int vb = blockIdx.x;
     Tile cur = decode(vb);
     make_plan(cur);
-    const float* __restrict__ ximg = x + (size_t)cur.img * H * W * Cin + (size_t)cur.ks * nchunks * 16;
-    const float* __restrict__ wblk = wp + ((size_t)cur.nb * nchunks_all + (size_t)cur.ks * nchunks) * (kBBytes / 4);   // [nb][chunk][pos][co][16]
+    const float* __restrict__ ximg = x + (size_t)cur.img * H * W * Cin + (size_t)cur.c0 * 16;
+    const float* __restrict__ wblk = wp + ((size_t)cur.nb * nchunks_all + (size_t)cur.c0) * (kBBytes / 4);   // [nb][chunk][pos][co][16]
 #pragma unroll
     for (int r = 0; r < kARounds; ++r) { WINO_LOAD_A_ROUND(ximg, 0, r, plan[r * kThreads]) }
 #pragma unroll
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
     for (;;) {
-        const bool is_last = c + 1 == nchunks;
+        const bool is_last = c + 1 == cur.nc;
         bool has_more = true;
         int vb_next = vb;
         Tile nxt = cur;
@@ -470,10 +475,10 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
             if (has_more) {
                 nxt = decode(vb_next);
 #if !(WINO_ABL & 4)
-                make_plan(nxt);
+                if (nxt.y0 != cur.y0 || nxt.x0 != cur.x0) make_plan(nxt);
 #endif      // the current tile's plan issued its last round in q0 of the previous chunk
-                a_next = x + (size_t)nxt.img * H * W * Cin + (size_t)nxt.ks * nchunks * 16;
-                b_next = wp + ((size_t)nxt.nb * nchunks_all + (size_t)nxt.ks * nchunks) * (kBBytes / 4);
+                a_next = x + (size_t)nxt.img * H * W * Cin + (size_t)nxt.c0 * 16;
+                b_next = wp + ((size_t)nxt.nb * nchunks_all + (size_t)nxt.c0) * (kBBytes / 4);
             }
         }
         const unsigned char* abuf = lds_a + par * kABytes;
@@ -665,8 +670,8 @@ int holo_conv3x3_wino_splitk_f32(const float* x_nhwc, const float* w_packed, con
                  "holo_conv3x3_wino_splitk_f32: batch=%d h=%d w=%d (reflection padding needs h,w >= 2)", batch, h, w);
     HOLO_REQUIRE(cin >= 32 && cin % 16 == 0 && cout > 0 && cout % 32 == 0, HOLO_ERR_UNSUPPORTED,
                  "holo_conv3x3_wino_splitk_f32: Cin=%d must be a multiple of 16 (at least 32) and Cout=%d a multiple of 32", cin, cout);
-    HOLO_REQUIRE(ksplit >= 2 && ksplit <= 8 && (cin / 16) % ksplit == 0 && (cin / 16) / ksplit >= 2, HOLO_ERR_UNSUPPORTED,
-                 "holo_conv3x3_wino_splitk_f32: ksplit=%d must be in [2,8] and divide the %d channel chunks into parts of at least 2",
+    HOLO_REQUIRE(ksplit >= 2 && ksplit <= 8 && (cin / 16) / ksplit >= 2, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv3x3_wino_splitk_f32: ksplit=%d must be in [2,8] and leave every part at least 2 of the %d channel chunks",
                  ksplit, cin / 16);
     HOLO_REQUIRE(!pool || relu, HOLO_ERR_UNSUPPORTED, "holo_conv3x3_wino_splitk_f32: fused pooling requires relu");
     HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < (1L << 30), HOLO_ERR_UNSUPPORTED,

@@ -100,24 +100,43 @@ class Plan:
         self.conv_algo = conv_algo  # fp32 3x3 layers: "direct" (implicit GEMM), "winograd" (F(2x2,3x3)), "auto" (by size)
         self._packed = {}
 
-    # Winograd blocks are 32 x 16 pixels x 32 channels, one per CU (256 of them): measured over batch 1..64 at 128^2 and 256^2
-    # (scripts/algo_sweep.sh) it wins from about half a wave of blocks up; below that the direct kernel's smaller tiles
-    # fill the chip better.  The two kernels differ by fp32 rounding (3e-5 of the outputs at 256^2), so the choice must not
-    # follow the exact batch size — a hologram would change with the shard it arrives in.  "auto" therefore decides from
-    # PER-IMAGE quantities (H, W, Cout) and a coarse batch BUCKET (1, 4 or 16 holograms: the largest of these not above
-    # the batch): every batch of 16 or more — all shards of a multi-GPU job, every micro-batch of the bench — makes the
-    # same choice, and so do all batches inside [4, 16) and inside [1, 4).
+    # Winograd work items are 32 x 16 pixels x 32 channels on a persistent grid of one block per CU (256): measured over batch
+    # 1..64 at 128^2 and 256^2 (scripts/algo_sweep.sh) the kernel wins from about half a wave of items up; below that the direct
+    # kernel's smaller tiles fill the chip better.  The two kernels differ by fp32 rounding (3e-5 of the outputs at 256^2), so the
+    # choice must not follow the exact batch size — a hologram would change with the shard it arrives in.  "auto" therefore
+    # decides from PER-IMAGE quantities (H, W, Cin, Cout) and the batch the launch is PLANNED for: the top of the bucket
+    # [1], [2], [3..5], [6..8], [9..12], [13..] that holds the batch (16 for the last one).  Every batch of 13 or more — all shards
+    # of a multi-GPU job, every micro-batch of the bench — makes the same choice, and so do the batches inside each smaller bucket;
+    # planning for the top means the real launch never has more work items than the plan assumed.
     WINO_MIN_BLOCKS = 128
-    BATCH_BUCKETS = (16, 4, 1)
+    BATCH_TOPS = (1, 2, 5, 8, 12, 16)
 
     @classmethod
     def batch_bucket(cls, b):
-        return next((k for k in cls.BATCH_BUCKETS if b >= k), 1)
+        return next((t for t in cls.BATCH_TOPS if b <= t), cls.BATCH_TOPS[-1])
 
-    # split-K (ops.conv3x3_wino(ksplit=...)): a layer short of blocks deals its channel chunks to 2, 4 or 8 work items per tile, each
-    # summing at least 4 chunks (64 channels); chosen, like the algorithm, from per-image quantities and the batch bucket
-    KSPLITS = (2, 4, 8)
-    KSPLIT_MIN_CHUNKS = 4
+    # split-K (ops.conv3x3_wino(ksplit=...)): a layer short of work items deals the Cin/16 channel chunks of every tile to k <= 8
+    # items (parts of at least 2 chunks, sizes differing by at most one).  k minimises a cost model of the launch, in microseconds
+    # as measured on MI355X (scripts/wino_ksplit_sweep.py, scripts/wino_stamps.py: an item costs 8 us + 4.4 us per chunk whether
+    # the grid is full or not; the reduction pass 3 us + its traffic at 4 TB/s): rounds of the persistent grid x the longest item,
+    # plus the reduction.  Typical outcome: the k that brings the item count closest to the CU count from below.
+    CUS = 256
+    KSPLIT_MAX = 8
+    KSPLIT_MIN_CHUNKS = 2
+    ITEM_US, CHUNK_US, REDUCE_US, REDUCE_BYTES_PER_US = 8.0, 4.4, 3.0, 4.0e6
+
+    @classmethod
+    def _ksplit(cls, items, chunks, out_bytes):
+        """k in [1, KSPLIT_MAX] with the lowest modelled time for `items` tiles x channel blocks of `chunks` chunks each."""
+        best_k, best_t = 1, -(-items // cls.CUS) * (cls.ITEM_US + cls.CHUNK_US * chunks)
+        for k in range(2, cls.KSPLIT_MAX + 1):
+            if chunks // k < cls.KSPLIT_MIN_CHUNKS:
+                break
+            t = (-(-items * k // cls.CUS) * (cls.ITEM_US + cls.CHUNK_US * -(-chunks // k))
+                 + cls.REDUCE_US + (k + 1) * out_bytes / cls.REDUCE_BYTES_PER_US)
+            if t < best_t:
+                best_k, best_t = k, t
+        return best_k
 
     def _wino_choice(self, step, x):
         """(use the Winograd kernel, ksplit) for a 3x3 step on input x (NHWC)."""
@@ -126,13 +145,13 @@ class Plan:
         if self.conv_algo == "winograd":
             return True, 1
         b, h, w, _ = x.shape
-        blocks = self.batch_bucket(b) * ((h + 31) // 32) * ((w + 15) // 16) * (step.conv.out_channels // 32)
-        if blocks >= self.WINO_MIN_BLOCKS:
-            return True, 1
-        chunks = step.conv.in_channels // 16
-        for k in self.KSPLITS:
-            if chunks % k == 0 and chunks // k >= self.KSPLIT_MIN_CHUNKS and blocks * k >= self.WINO_MIN_BLOCKS:
-                return True, k
+        planned = self.batch_bucket(b)
+        items = planned * ((h + 31) // 32) * ((w + 15) // 16) * (step.conv.out_channels // 32)
+        # the open-ended top bucket is never split: a batch of 256 would carry the reduction pass a batch of 16 asked for
+        k = 1 if planned == self.BATCH_TOPS[-1] else self._ksplit(items, step.conv.in_channels // 16,
+                                                                  4.0 * planned * h * w * step.conv.out_channels)
+        if items * k >= self.WINO_MIN_BLOCKS:
+            return True, k
         return False, 1
 
     def _use_winograd(self, step, x):

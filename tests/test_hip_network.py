@@ -133,12 +133,12 @@ def test_full_size_properties(env, mnist_style):
                 assert torch.equal(amp[2:5], amp2) and torch.equal(p[2:5], p2) and torch.equal(dist[2:5], dist2), algo
         finally:
             network.set_conv_algo("auto")
-        # "auto": the choice follows per-image quantities and a coarse batch bucket (engine.Plan.BATCH_BUCKETS: 1 / 4 / 16), so
-        # batches of 8 and 5 holograms (one bucket) agree bit for bit; across a bucket edge (8 vs 3) the two algorithms'
-        # fp32 rounding shows, measured 3.4e-5
+        # "auto": the choice follows per-image quantities and the batch bucket (engine.Plan.BATCH_TOPS: 1 | 2 | 3-5 | 6-8 | 9-12 | 13+),
+        # so batches of 8 and 6 holograms (one bucket) agree bit for bit; across a bucket edge (8 vs 3) the algorithms' and the
+        # splits' fp32 rounding shows, measured 3.4e-5
         amp, p, dist = network.field_retrieval(content, mnist_style.to(dev), 1.0, True)
-        amp5, p5, dist5 = network.field_retrieval(content[2:7], mnist_style.to(dev), 1.0, True)
-        assert torch.equal(amp[2:7], amp5) and torch.equal(p[2:7], p5) and torch.equal(dist[2:7], dist5)
+        amp6, p6, dist6 = network.field_retrieval(content[2:8], mnist_style.to(dev), 1.0, True)
+        assert torch.equal(amp[2:8], amp6) and torch.equal(p[2:8], p6) and torch.equal(dist[2:8], dist6)
         amp2, p2, dist2 = network.field_retrieval(content[2:5], mnist_style.to(dev), 1.0, True)
         assert rel_err(amp2.cpu(), amp[2:5].cpu()) < 5e-5 and rel_err(p2.cpu(), p[2:5].cpu()) < 5e-5
         a0, p0 = network.field_retrieval(content[:2], mnist_style.to(dev), 0.0)

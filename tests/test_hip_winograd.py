@@ -148,10 +148,10 @@ def test_auto_picks_winograd_only_for_layers_that_fill_the_chip(dev):
     big = torch.empty(64, 32, 32, conv.conv.in_channels, device="meta")
     small = torch.empty(2, 16, 16, conv.conv.in_channels, device="meta")
     assert plan._use_winograd(conv, big)
-    assert plan._wino_choice(conv, small) == (True, 8)                   # 512 -> 512: 16 blocks x 8 parts of 4 chunks = half a wave
-    assert plan._wino_choice(conv, torch.empty(5, 16, 16, conv.conv.in_channels, device="meta")) == (True, 2)   # split-K instead
+    assert plan._wino_choice(conv, small) == (True, 8)                   # 512 -> 512: 32 items x 8 parts of 4 chunks = one full round
+    assert plan._wino_choice(conv, torch.empty(5, 16, 16, conv.conv.in_channels, device="meta")) == (True, 3)   # 80 items x 3 parts
     c256 = next(s for s in plan.steps if s.kind == "conv" and s.conv.in_channels == 256 and s.conv.out_channels == 256)
-    assert not plan._use_winograd(c256, torch.empty(2, 16, 16, 256, device="meta"))   # 8 blocks: no admissible split reaches the threshold
+    assert not plan._use_winograd(c256, torch.empty(1, 16, 16, 256, device="meta"))   # 8 items: no admissible split reaches half a wave
     plan.conv_algo = "direct"
     assert not plan._use_winograd(conv, big)
     plan.conv_algo = "winograd"
@@ -168,6 +168,11 @@ def test_auto_picks_winograd_only_for_layers_that_fill_the_chip(dev):
     (2, 5, 5, 128, 32, True, True, 4),
     (1, 2, 2, 64, 64, False, False, 2),        # smallest legal image, no activation
     (2, 40, 24, 256, 96, False, False, 8),     # 16 chunks in 8 parts of 2: the smallest part the entry point accepts
+    (5, 32, 32, 256, 256, True, False, 3),     # uneven parts (what `auto` picks at 5 x 128^2): 16 chunks as 5 + 5 + 6
+    (5, 16, 16, 512, 256, True, False, 6),     # 32 chunks as 5 5 6 5 5 6
+    (5, 16, 16, 512, 512, True, False, 3),     # 10 + 11 + 11
+    (3, 20, 18, 112, 64, True, True, 3),       # 7 chunks as 2 + 2 + 3, partial tiles, pooling
+    (2, 9, 33, 80, 32, False, False, 2),       # 5 chunks as 2 + 3
 ])
 def test_conv3x3_winograd_splitk(ops, dev, b, h, w, cin, cout, relu, pool, ksplit):
     """Split-K: the channel chunks of a tile dealt to `ksplit` work items + the fixed-order reduction (bias, ReLU, pooling in
@@ -196,8 +201,9 @@ def test_validation_winograd_splitk():
     args = lambda cin, cout, k, ws=big: (fake, fake, fake, fake, 1, 4, 4, cin, cout, 1, 0, k, fake, ws, None)  # noqa: E731
     assert lib.holo_conv3x3_wino_splitk_f32(None, fake, fake, fake, 1, 4, 4, 64, 32, 1, 0, 2, fake, big, None) == 1
     assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 1)) == 2          # ksplit < 2
-    assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 3)) == 2          # 4 chunks do not divide by 3
+    assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 3)) == 2          # 4 chunks in 3 parts: one part of a single chunk
     assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 4)) == 2          # parts of one chunk
+    assert lib.holo_conv3x3_wino_splitk_f32(*args(512, 32, 9)) == 2         # ksplit > 8
     assert lib.holo_conv3x3_wino_splitk_f32(*args(96, 48, 2)) == 2          # Cout % 32
     assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 2, 16)) == 3      # workspace
     assert lib.holo_conv3x3_wino_splitk_workspace_bytes(5, 32, 32, 256, 2) == 2 * 5 * 32 * 32 * 256 * 4

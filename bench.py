@@ -145,6 +145,7 @@ def main():
     # with several ranks on ONE card (the one-GPU development box)
     backend = os.environ.get("HOLO_DIST_BACKEND", "nccl")
     rank, world, local = shard.init_from_env(backend)
+    dist_on = world > 1 or shard.force_collectives()     # HOLO_FORCE_DIST=1: one rank, but through the collective path all the same
     if os.environ.get("HOLO_SHARE_GPU") == "1":
         local = min(local, torch.cuda.device_count() - 1)
     if world != args.gpus:
@@ -210,7 +211,7 @@ def main():
     def step_weak():
         with torch.no_grad():
             amp, p, d, a_f, p_f = one_batch(content, d_style)
-            if world > 1 and args.distances == 1:
+            if dist_on and args.distances == 1:
                 # the step's one exchange: started here, waited for one step later, so it rides under the next
                 # step's kernels; sync() drains the last one inside the timed region
                 pending.append(shard.gather_to_root(shard.pack_outputs(amp, p, a_f, p_f, d), async_op=True))
@@ -241,7 +242,7 @@ def main():
         while pending:
             pending.pop(0).wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -276,14 +277,14 @@ def main():
                 step()
         sync()
         elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         total = (args.total if args.total else b * world) * args.steps
-        coll = {"nccl": "RCCL"}.get(backend, backend) if world > 1 else "none (single rank)"
+        coll = {"nccl": "RCCL"}.get(backend, backend) if dist_on else "none (single rank)"
         cfg_no = 3 if args.total else (2 if args.dtype == "bf16" else 1)
         per_gpu = f"{args.total} holograms in all, contiguous blocks of {-(-args.total // world)} per GPU in micro-batches of {b}" if args.total else f"batch {b}/GPU"
         out = {
@@ -295,7 +296,7 @@ def main():
                                    f"{ {'f32': 'fp32', 'bf16': 'bf16 convs / fp32 FFT', 'f32s': 'convs on split-fp16 operands (hi + lo*2^-11, fp32 accumulate; NOT fp32 arithmetic) / fp32 FFT'}[args.dtype] }, VGG-AdaIN-decoder + "
                                    f"distance head + angular-spectrum back-propagation (P={2 * s}), seeded He-normal weights",
                        "batch_per_gpu": b, "size": s, "distances_per_field": args.distances, "style": args.style, "hipgraph": bool(args.graph), "conv_algo": args.conv_algo, "total_holograms": args.total or b * world,
-                       "parallelism": f"batch-sharded x{world}, one {coll} gather per step" if world > 1 else "single GPU"},
+                       "parallelism": f"batch-sharded x{world}, one {coll} gather per step" if dist_on else "single GPU"},
         }
         if timer is not None:
             summ = timer.summary()
@@ -387,7 +388,7 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(s, sds, style_cpu, args.cpu_sample, seed)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

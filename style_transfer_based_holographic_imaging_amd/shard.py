@@ -21,12 +21,18 @@ def shard_bounds(n: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def force_collectives() -> bool:
+    """HOLO_FORCE_DIST=1: initialise the process group and run the gather even with ONE rank, so that the RCCL path (backend
+    start-up, device binding, the asynchronous gather and its wait) executes on a one-GPU box (tests/test_hip_rccl.py)."""
+    return os.environ.get("HOLO_FORCE_DIST") == "1"
+
+
 def init_from_env(backend: str | None = None):
-    """(rank, world, local_rank); initialises the process group when WORLD_SIZE > 1."""
+    """(rank, world, local_rank); initialises the process group when WORLD_SIZE > 1 (or when HOLO_FORCE_DIST=1)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -109,7 +115,7 @@ def gather_to_root(packed: torch.Tensor, counts: list[int] | None = None, dst: i
     """One gather of every rank's packed block to ``dst``.  Returns the concatenated (N_total, F)
     tensor on ``dst`` and None elsewhere (``async_op``: a ``PendingGather`` whose ``wait()`` returns that).
     ``counts`` (rows per rank) allows ragged shards: blocks are padded to the largest and trimmed on the root."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collectives()):
         return PendingGather(None, packed, None, True, None) if async_op else packed
     world, rank = dist.get_world_size(), dist.get_rank()
     counts = counts or [packed.shape[0]] * world

@@ -207,3 +207,31 @@ def test_validation_winograd_splitk():
     assert lib.holo_conv3x3_wino_splitk_f32(*args(96, 48, 2)) == 2          # Cout % 32
     assert lib.holo_conv3x3_wino_splitk_f32(*args(64, 32, 2, 16)) == 3      # workspace
     assert lib.holo_conv3x3_wino_splitk_workspace_bytes(5, 32, 32, 256, 2) == 2 * 5 * 32 * 32 * 256 * 4
+
+
+def test_random_shapes_all_three_kernels(ops, dev):
+    """Seeded sweep over 36 random layer shapes (sizes 2..75 incl. odd ones, every channel count the kernels accept, batch 1..6,
+    every admissible split): direct kernel, Winograd and split-K Winograd against torch-CPU fp32, and each against the others."""
+    import random
+    rng = random.Random(20261004)
+    for case in range(36):
+        b = rng.randint(1, 6)
+        h, w = rng.randint(2, 75), rng.randint(2, 75)
+        cin = 16 * rng.choice([2, 3, 4, 5, 7, 8, 12, 16])
+        cout = 64 * rng.choice([1, 1, 2, 3, 4])
+        relu = rng.random() < 0.8
+        pool = relu and rng.random() < 0.4
+        x, wt, bias = _case(9000 + case, b, h, w, cin, cout, scale=rng.choice([0.1, 1.0, 30.0]))
+        ref = _ref(x, wt, bias, relu, pool)
+        xp, bd = ops.to_nhwc(x.to(dev)), bias.to(dev)
+        ww, wd = ops.pack_conv3x3_wino(wt.to(dev)), ops.pack_conv3x3(wt.to(dev), torch.float32)
+        tag = f"case {case}: b={b} {h}x{w} {cin}->{cout} relu={relu} pool={pool}"
+        outs = {"direct": ops.conv3x3(xp, wd, bd, cout, relu, pool), "wino": ops.conv3x3_wino(xp, ww, bd, cout, relu, pool)}
+        ks = [k for k in range(2, 9) if (cin // 16) // k >= 2]
+        if ks:
+            k = rng.choice(ks)
+            outs[f"splitk{k}"] = ops.conv3x3_wino(xp, ww, bd, cout, relu, pool, ksplit=k)
+        for name, y in outs.items():
+            got = ops.as_nchw_view(y).cpu()
+            assert got.shape == ref.shape, f"{tag} {name}"
+            assert rel_err(got, ref) < 4e-6, f"{tag} {name}: {rel_err(got, ref):.2e}"

@@ -82,6 +82,19 @@ __device__ __forceinline__ v4f sub4(v4f a, v4f b) {
     const v2f hi = sub2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
+// a + b on quads as two packed instructions.  hipcc lowers the float4 `b + c` of the patch transform to four v_add_f32; beside
+// v_mfma_f32_32x32x2_f32 — which runs on the vector ALU's own FMA lanes, so nothing issued to the vector ALU hides behind it
+// (scripts/mfma_f32_valu_overlap.hip: 64 + 8 N cycles per MFMA with N v_add_f32 after it, 64 + 5.5 N with v_pk_add_f32) — an
+// unpacked instruction costs 8 cycles for one value, a packed one 5.5 for two.  (There is no packed fp32 max on gfx950.)
+__device__ __forceinline__ v4f add4(v4f a, v4f b) {
+#ifdef WINO_AB_OLD
+    return a + b;
+#endif
+    v2f lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 template <typename V16>
 __device__ __forceinline__ V16 sub16(V16 a, V16 b) {
     V16 d;
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     // VALU instructions of every bt4).  Measured: 18.5 -> 18.3 ms of Winograd time per step (+1.5 % holograms/s).
     auto bt4 = [&](vecw a, vecw b, vecw c, vecw e, vecw& o0, vecw& o1, vecw& o2, vecw& o3) {
         o0 = wino::sub4(a, c);
-        o1 = b + c;
+        o1 = wino::add4(b, c);
         o2 = wino::sub4(c, b);
         o3 = wino::sub4(b, e);
     };

@@ -87,9 +87,6 @@ __device__ __forceinline__ v4f sub4(v4f a, v4f b) {
 // (scripts/mfma_f32_valu_overlap.hip: 64 + 8 N cycles per MFMA with N v_add_f32 after it, 64 + 5.5 N with v_pk_add_f32) — an
 // unpacked instruction costs 8 cycles for one value, a packed one 5.5 for two.  (There is no packed fp32 max on gfx950.)
 __device__ __forceinline__ v4f add4(v4f a, v4f b) {
-#ifdef WINO_AB_OLD
-    return a + b;
-#endif
     v2f lo, hi;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(__builtin_shufflevector(a, a, 0, 1)), "v"(__builtin_shufflevector(b, b, 0, 1)));
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(__builtin_shufflevector(a, a, 2, 3)), "v"(__builtin_shufflevector(b, b, 2, 3)));

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 3
+#define HOLO_ABI_VERSION 4
 
 /* error codes */
 #define HOLO_OK 0
@@ -131,6 +131,17 @@ int holo_rownorm_relu_f32(const float* x, float* y, int batch, int n, float eps,
 /* y = sigmoid(bias + x . w) for the final Linear(512,1) */
 int holo_linear1_sigmoid_f32(const float* x, const float* w, const float* bias, float* y, int batch,
                              int k, void* stream);
+
+/* The whole head (Distance_G.forward in eval mode, net.py:288-308) on the statistics (B,c) `mean`, `std` in four launches: the input
+ * concatenation is read in place and every InstanceNorm1d + ReLU is applied by the Linear that consumes it (each wave holds its input
+ * rows in registers and computes their mean / biased variance itself).  Layer shapes as in the reference: w1, w2 (2c,2c), w3 (c,2c),
+ * wo (1,c), row-major; out: (B); workspace: holo_distance_head_workspace_bytes = 2 * B * 2c floats.  c % 256 == 0, 2c <= 1024 (the
+ * reference has c = 512); other widths take the three per-layer entry points above.  Differs from them by fp32 rounding only (the
+ * statistics are summed in a different order). */
+size_t holo_distance_head_workspace_bytes(int batch, int c);
+int holo_distance_head_f32(const float* mean, const float* std, const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* w3, const float* b3, const float* wo, const float* bo, float* out, int batch, int c, float eps,
+                           float* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Angular-spectrum propagation (utils/Angular_Spectrum_Method.py:7-53 + the field packing and

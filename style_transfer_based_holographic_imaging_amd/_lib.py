@@ -48,6 +48,8 @@ SIGNATURES = {
     "holo_linear_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_rownorm_relu_f32": (_i, [_p, _p, _i, _i, _f, _p]),
     "holo_linear1_sigmoid_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "holo_distance_head_workspace_bytes": (_z, [_i, _i]),
+    "holo_distance_head_f32": (_i, [_p] * 11 + [_i, _i, _f, _p, _z, _p]),
     "holo_asm_phase_constants_f32": (_i, [_p, _l, _i, _f, _f, _p, _i, _p]),
     "holo_asm_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "holo_asm_propagate": (_i, [_p, _p, _i, _l, _l, _p, _p, _i, _l, _l, _p, _i, _i, _i, _i, _d, _d, _f, _p, _z, _p]),
@@ -79,7 +81,7 @@ SIGNATURES = {
 
 ASM_IN_AMP_PHASE, ASM_IN_COMPLEX = 0, 1
 ASM_OUT_AMP_PHASE, ASM_OUT_INTENSITY, ASM_OUT_COMPLEX = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HoloLibraryError(RuntimeError):

@@ -92,9 +92,193 @@ __global__ __launch_bounds__(256) void linear1_sigmoid_kernel(const float* __res
     if (lane == 0) y[b] = 1.0f / (1.0f + expf(-(acc + bias[0])));
 }
 
+// ---- the whole head in four launches (holo_distance_head_f32) -----------------------------------------------------------------------
+// At small batches the head is launch latency: Linear, norm+ReLU, Linear, norm+ReLU, Linear, norm+ReLU, Linear+sigmoid and the
+// concatenation in front are 8 launches of 4-7 us for 10 MB of weights.  Here the normalisation moves into the CONSUMER: a block of
+// the next Linear stages its 8 input rows in LDS anyway, so the wave that fetches a row computes its mean and biased variance itself
+// (two passes over its registers, lane-sequential partial sums, xor butterfly: every lane ends with the same value) and stores
+// (x - mu) / sqrt(var + eps), ReLU'd; the first Linear reads its row from the two statistics tensors.
+// Same arithmetic per sample whatever its slot or batch: one fmaf chain per slot, fixed summation trees.
+constexpr int kHeadMaxK = 1024;   // input features of a normalising layer (registers: 8 rows x k/64 values)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// NORM: the input rows are raw Linear outputs, normalised + ReLU'd on load.  TWO: row b = [x[b][0..k1) | x2[b][0..k-k1)].
+// A block = 8 samples x 16 output features: its four waves first bring the 8 input rows into LDS (two rows per wave, normalised
+// there if NORM), then every wave runs 4 features against all 8 rows — a row is fetched (and normalised) once per block and 16
+// features instead of once per wave and feature, and a lane has its 16 weight loads in flight at once.
+constexpr int kHeadFeat = 4;      // output features per wave
+template <bool NORM, bool TWO>
+__global__ __launch_bounds__(256) void head_linear_kernel(const float* __restrict__ x, const float* __restrict__ x2, int k1,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int batch, int k, int n, float eps) {
+    __shared__ __attribute__((aligned(16))) float rows[kBT][kHeadMaxK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = blockIdx.y * kBT;
+    constexpr int kQ = kHeadMaxK / 256;    // float4 steps per lane and row
+    // ---- the block's 8 rows -> LDS (wave w: rows 2w, 2w+1) ----
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int i = 2 * wave + i2;
+        const int b = b0 + i < batch ? b0 + i : batch - 1;
+        float4 xv[kQ];
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const int kk = lane * 4 + 256 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < k) {
+                if (TWO) v = kk < k1 ? *reinterpret_cast<const float4*>(x + (size_t)b * k1 + kk)
+                                     : *reinterpret_cast<const float4*>(x2 + (size_t)b * (k - k1) + (kk - k1));
+                else v = *reinterpret_cast<const float4*>(x + (size_t)b * k + kk);
+            }
+            xv[q] = v;
+        }
+        if (NORM) {
+            float s = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q)
+                if (lane * 4 + 256 * q < k) s += (xv[q].x + xv[q].y) + (xv[q].z + xv[q].w);
+            const float mu = wave_sum(s) / (float)k;
+            float qs = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q)
+                if (lane * 4 + 256 * q < k) {
+                    const float dx = xv[q].x - mu, dy = xv[q].y - mu, dz = xv[q].z - mu, dw = xv[q].w - mu;
+                    qs += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                }
+            const float inv = 1.0f / sqrtf(wave_sum(qs) / (float)k + eps);
+#pragma unroll
+            for (int q = 0; q < kQ; ++q)
+                xv[q] = make_float4(fmaxf((xv[q].x - mu) * inv, 0.0f), fmaxf((xv[q].y - mu) * inv, 0.0f),
+                                    fmaxf((xv[q].z - mu) * inv, 0.0f), fmaxf((xv[q].w - mu) * inv, 0.0f));
+        }
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) *reinterpret_cast<float4*>(&rows[i][lane * 4 + 256 * q]) = xv[q];
+    }
+    __syncthreads();
+    // ---- 4 features per wave against the 8 rows ----
+    const int on0 = (blockIdx.x * 4 + wave) * kHeadFeat;
+    float acc[kHeadFeat][kBT];
+#pragma unroll
+    for (int f = 0; f < kHeadFeat; ++f)
+#pragma unroll
+        for (int i = 0; i < kBT; ++i) acc[f][i] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+        const int kk = lane * 4 + 256 * q;
+        if (kk < k) {
+            float4 wv[kHeadFeat];
+#pragma unroll
+            for (int f = 0; f < kHeadFeat; ++f) {
+                const int on = on0 + f < n ? on0 + f : n - 1;
+                wv[f] = *reinterpret_cast<const float4*>(w + (size_t)on * k + kk);
+            }
+#pragma unroll
+            for (int i = 0; i < kBT; ++i) {
+                const float4 xv = *reinterpret_cast<const float4*>(&rows[i][kk]);
+#pragma unroll
+                for (int f = 0; f < kHeadFeat; ++f) {   // one explicit FMA chain per (feature, sample slot), as in linear_kernel
+                    acc[f][i] = fmaf(xv.x, wv[f].x, acc[f][i]);
+                    acc[f][i] = fmaf(xv.y, wv[f].y, acc[f][i]);
+                    acc[f][i] = fmaf(xv.z, wv[f].z, acc[f][i]);
+                    acc[f][i] = fmaf(xv.w, wv[f].w, acc[f][i]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < kHeadFeat; ++f)
+#pragma unroll
+        for (int i = 0; i < kBT; ++i) acc[f][i] = wave_sum(acc[f][i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int f = 0; f < kHeadFeat; ++f)
+            if (on0 + f < n) {
+                const float bv = bias[on0 + f];
+#pragma unroll
+                for (int i = 0; i < kBT; ++i)
+                    if (b0 + i < batch) y[(size_t)(b0 + i) * n + on0 + f] = acc[f][i] + bv;
+            }
+    }
+}
+
+// one wave per sample: sigmoid(bias + relu(norm(x)) . w), x the raw output of the third Linear
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int batch, int k,
+                                                       float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= batch) return;
+    constexpr int kQ = kHeadMaxK / 256;
+    float4 xv[kQ];
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+        const int kk = lane * 4 + 256 * q;
+        xv[q] = kk < k ? *reinterpret_cast<const float4*>(x + (size_t)b * k + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < k) s += (xv[q].x + xv[q].y) + (xv[q].z + xv[q].w);
+    }
+    const float mu = wave_sum(s) / (float)k;
+    float qs = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q)
+        if (lane * 4 + 256 * q < k) {
+            const float dx = xv[q].x - mu, dy = xv[q].y - mu, dz = xv[q].z - mu, dw = xv[q].w - mu;
+            qs += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    const float inv = 1.0f / sqrtf(wave_sum(qs) / (float)k + eps);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+        const int kk = lane * 4 + 256 * q;
+        if (kk < k) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + kk);
+            acc = fmaf(fmaxf((xv[q].x - mu) * inv, 0.0f), wv.x, acc);
+            acc = fmaf(fmaxf((xv[q].y - mu) * inv, 0.0f), wv.y, acc);
+            acc = fmaf(fmaxf((xv[q].z - mu) * inv, 0.0f), wv.z, acc);
+            acc = fmaf(fmaxf((xv[q].w - mu) * inv, 0.0f), wv.w, acc);
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[b] = 1.0f / (1.0f + expf(-(acc + bias[0])));
+}
+
 }  // namespace holo
 
 extern "C" {
+
+size_t holo_distance_head_workspace_bytes(int batch, int c) {
+    return batch > 0 && c > 0 ? (size_t)2 * batch * 2 * c * sizeof(float) : 0;
+}
+
+int holo_distance_head_f32(const float* mean, const float* std, const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* w3, const float* b3, const float* wo, const float* bo, float* out, int batch, int c, float eps,
+                           float* workspace, size_t workspace_bytes, void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(mean && std && w1 && b1 && w2 && b2 && w3 && b3 && wo && bo && out && workspace, HOLO_ERR_ARG,
+                 "holo_distance_head_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && c > 0, HOLO_ERR_ARG, "holo_distance_head_f32: batch=%d c=%d", batch, c);
+    HOLO_REQUIRE(c % 256 == 0 && 2 * c <= kHeadMaxK, HOLO_ERR_UNSUPPORTED,
+                 "holo_distance_head_f32: c=%d must be a multiple of 256 with 2c <= %d (use the per-layer entry points otherwise)", c, kHeadMaxK);
+    HOLO_REQUIRE(workspace_bytes >= holo_distance_head_workspace_bytes(batch, c), HOLO_ERR_WORKSPACE,
+                 "holo_distance_head_f32: workspace %zu < required %zu", workspace_bytes, holo_distance_head_workspace_bytes(batch, c));
+    const int by = ceil_div(batch, kBT);
+    HOLO_REQUIRE(by <= 65535, HOLO_ERR_UNSUPPORTED, "holo_distance_head_f32: batch %d too large for one call", batch);
+    const int f = 2 * c;
+    float* y1 = workspace;
+    float* y2 = workspace + (size_t)batch * f;
+    hipStream_t st = as_stream(stream);
+    constexpr int per_block = 4 * kHeadFeat;     // output features per block
+    hipLaunchKernelGGL((head_linear_kernel<false, true>), dim3(ceil_div(f, per_block), by), dim3(256), 0, st, mean, std, c, w1, b1, y1, batch, f, f, eps);
+    hipLaunchKernelGGL((head_linear_kernel<true, false>), dim3(ceil_div(f, per_block), by), dim3(256), 0, st, y1, nullptr, 0, w2, b2, y2, batch, f, f, eps);
+    hipLaunchKernelGGL((head_linear_kernel<true, false>), dim3(ceil_div(c, per_block), by), dim3(256), 0, st, y2, nullptr, 0, w3, b3, y1, batch, f, c, eps);
+    hipLaunchKernelGGL(head_out_kernel, dim3(ceil_div(batch, 4)), dim3(256), 0, st, y1, wo, bo, out, batch, c, eps);
+    return check_launch("holo_distance_head_f32");
+}
 
 int holo_linear_f32(const float* x, const float* w, const float* bias, float* y, int batch, int k, int n, void* stream) {
     using namespace holo;

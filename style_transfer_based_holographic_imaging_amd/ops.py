@@ -400,8 +400,23 @@ def linear1_sigmoid(x, w, bias):
     return y
 
 
-def distance_head(mean, std, sd):
-    """net.py:288-308 on (B,C) statistics; ``sd`` maps l1/l2/l3/out .weight/.bias to device tensors."""
+def distance_head(mean, std, sd, eps: float = 1e-5):
+    """net.py:288-308 on (B,C) statistics; ``sd`` maps l1/l2/l3/out .weight/.bias to device tensors.  The reference's widths
+    (C = 512) run as four launches (holo_distance_head_f32); any other width layer by layer."""
+    _req(mean, std)
+    bsz, c = mean.shape
+    shapes = [tuple(sd[f"{n}.weight"].shape) for n in ("l1", "l2", "l3", "out")]
+    if c % 256 == 0 and 2 * c <= 1024 and shapes == [(2 * c, 2 * c), (2 * c, 2 * c), (c, 2 * c), (1, c)]:
+        mean, std = _f32c(mean), _f32c(std)
+        prm = [_f32c(sd[f"{n}.{p}"].detach()) for n in ("l1", "l2", "l3", "out") for p in ("weight", "bias")]
+        _req(*prm)
+        ws_bytes = lib.holo_distance_head_workspace_bytes(bsz, c)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=mean.device)
+        y = torch.empty((bsz, 1), dtype=torch.float32, device=mean.device)
+        _launch("holo_distance_head_f32", lambda: lib.holo_distance_head_f32(
+            mean.data_ptr(), std.data_ptr(), *[t.data_ptr() for t in prm], y.data_ptr(), bsz, c, float(eps), ws.data_ptr(), ws_bytes, _stream()),
+                flops=2.0 * bsz * (2 * (2 * c) ** 2 + 2 * c * c + c), nbytes=4.0 * (2 * (2 * c) ** 2 + 2 * c * c + c))
+        return y
     x = torch.cat([mean, std], dim=1)
     for name in ("l1", "l2", "l3"):
         x = rownorm_relu(linear(x, sd[f"{name}.weight"], sd[f"{name}.bias"]))

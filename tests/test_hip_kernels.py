@@ -134,6 +134,47 @@ def test_distance_head(ops, dev, b, synth_weights):
     assert rel_err(got.cpu(), ref) < 2e-5
 
 
+def test_distance_head_four_launch_form_against_the_layer_by_layer_one(ops, dev, synth_weights):
+    """holo_distance_head_f32 (the normalisation inside the consuming Linear, the concatenation read in place) against the per-layer
+    entry points it replaces: same values up to the re-ordered statistics sums; a width it does not take (C = 128) goes layer by layer."""
+    dist_sd = synth_weights[2]
+    dsd = {k: v.to(dev) for k, v in dist_sd.items()}
+    g = _gen(77)
+    for b in (1, 5, 8, 9, 64):
+        mean, std = torch.randn(b, 512, generator=g).abs().to(dev), (torch.rand(b, 512, generator=g) + 0.1).to(dev)
+        got = ops.distance_head(mean, std, dsd)
+        x = torch.cat([mean, std], 1)
+        for name in ("l1", "l2", "l3"):
+            x = ops.rownorm_relu(ops.linear(x, dsd[f"{name}.weight"], dsd[f"{name}.bias"]))
+        ref = ops.linear1_sigmoid(x, dsd["out.weight"], dsd["out.bias"])
+        assert got.shape == ref.shape == (b, 1)
+        assert rel_err(got.cpu(), ref.cpu()) < 2e-6
+    c = 128
+    sd = {"l1.weight": torch.randn(2 * c, 2 * c, generator=g) * 0.1, "l1.bias": torch.zeros(2 * c), "l2.weight": torch.randn(2 * c, 2 * c, generator=g) * 0.1,
+          "l2.bias": torch.zeros(2 * c), "l3.weight": torch.randn(c, 2 * c, generator=g) * 0.1, "l3.bias": torch.zeros(c),
+          "out.weight": torch.randn(1, c, generator=g) * 0.1, "out.bias": torch.zeros(1)}
+    mean, std = torch.randn(3, c, generator=g).abs(), torch.rand(3, c, generator=g) + 0.1
+    got = ops.distance_head(mean.to(dev), std.to(dev), {k: v.to(dev) for k, v in sd.items()})
+    x = torch.cat([mean, std], 1)
+    for name in ("l1", "l2", "l3"):
+        x = torch.relu(torch.nn.functional.instance_norm((x @ sd[f"{name}.weight"].t() + sd[f"{name}.bias"]).unsqueeze(0)).squeeze(0))
+    ref = torch.sigmoid(x @ sd["out.weight"].t() + sd["out.bias"])
+    assert rel_err(got.cpu(), ref) < 2e-5
+
+
+def test_validation_distance_head():
+    import ctypes
+    from style_transfer_based_holographic_imaging_amd._lib import lib
+    fake = ctypes.c_void_p(16)
+    args = lambda b, c, ws: [fake] * 11 + [b, c, 1e-5, fake, ws, None]      # noqa: E731
+    assert lib.holo_distance_head_f32(*([None] + args(2, 512, 1 << 30)[1:])) == 1
+    assert lib.holo_distance_head_f32(*args(0, 512, 1 << 30)) == 1
+    assert lib.holo_distance_head_f32(*args(2, 128, 1 << 30)) == 2          # c not a multiple of 256
+    assert lib.holo_distance_head_f32(*args(2, 768, 1 << 30)) == 2          # 2c > 1024
+    assert lib.holo_distance_head_f32(*args(2, 512, 16)) == 3               # workspace
+    assert lib.holo_distance_head_workspace_bytes(5, 512) == 2 * 5 * 1024 * 4
+
+
 def test_layout_roundtrip(ops, dev):
     x = torch.randn(3, 70, 9, 11, generator=_gen(5))
     y = ops.to_nhwc(x.to(dev))

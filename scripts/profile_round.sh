@@ -27,6 +27,8 @@ HOLO_DIST_BACKEND=gloo HOLO_SHARE_GPU=1 python -m torch.distributed.run --nnodes
 for a in auto direct winograd; do
   python bench.py --batch 5 --size 128 --cpu-sample 0 --conv-algo $a --steps 50 --warmup 10 2>/dev/null > $O/${R}_bench_b5_$a.json
 done
+python bench.py --batch 5 --size 128 --cpu-sample 0 --steps 200 --warmup 20 --no-events 2>/dev/null > $O/${R}_bench_b5_auto_noevents.json    # the step without a HIP event pair around each of its 45 launches
+python bench.py --batch 1 --size 256 --cpu-sample 0 --steps 200 --warmup 20 --no-events 2>/dev/null > $O/${R}_bench_b1_s256_noevents.json
 python scripts/per_layer.py --batch 5 --size 128 --reps 20 > $O/${R}_layers_b5.txt 2>&1
 fi
 R_=$R python - <<'PY'

@@ -40,3 +40,6 @@ for b, c, hw in shapes:
     for i, n in enumerate(names):
         per = out[i] / (chunks if i < 5 else tiles)
         print(f"   {n:18s} {out[i]:12d} ticks  {100 * out[i] / tot:5.1f} %   {per:9.0f} per {'chunk' if i < 5 else 'tile'}")
+    # inside the epilogue (the "epilogue" line above is only its last part when these are present)
+    for i, n in ((9, "epilogue: addressing, bias request, nops"), (10, "epilogue: accumulator reads + output transform")):
+        print(f"   {n:48s} {out[i] / tiles:9.0f} per tile")

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+#if WINO_STAMPS
+    unsigned long long t_last = 0;
+#endif
     const int n_blk = Cout / kTN;
     const int nchunks_all = Cin / 16;            // chunks of the layer (stride of the packed weights)
 
@@ -341,10 +344,12 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
         // the two files inside the MFMA loop.  The last MFMAs of the tile were issued before the step's closing barrier; the
         // s_nops cover the 16-pass MFMA -> AGPR read hazard, which hipcc does not pad for an asm statement.
         // the bias quads are requested first: their latency hides behind the accumulator reads and the transform
+        const float act_lo = relu ? 0.0f : -__builtin_inff();
         float4 bq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = bias ? *reinterpret_cast<const float4*>(bias + co0 + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);   // split-K partials carry no bias
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        WSTAMP(9)    // addressing, bias request, hazard nops
         auto rd_tile = [&](const floatx16& t) {
             floatx16 v;
 #pragma unroll
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
                 o11 = sub16(o11, u1);
             }
         }
+        WSTAMP(10)   // accumulator reads + A^T M A
         // The product is computed TRANSPOSED (weights as the A operand): lane = tile li, register r = channel
         // (r&3) + 8*(r>>2) + 4*hsel of the block's 32, so a quad of registers is 4 consecutive channels = one 16-byte piece of an
         // NHWC pixel: 16 global_store_dwordx4 per lane instead of 64 global_store_dword (the epilogue is store-issue bound).
@@ -400,13 +406,13 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
             o[0][1] = make_float4(o01[4 * q] + b4.x, o01[4 * q + 1] + b4.y, o01[4 * q + 2] + b4.z, o01[4 * q + 3] + b4.w);
             o[1][0] = make_float4(o10[4 * q] + b4.x, o10[4 * q + 1] + b4.y, o10[4 * q + 2] + b4.z, o10[4 * q + 3] + b4.w);
             o[1][1] = make_float4(o11[4 * q] + b4.x, o11[4 * q + 1] + b4.y, o11[4 * q + 2] + b4.z, o11[4 * q + 3] + b4.w);
-            if (relu) {
+            // ReLU without a branch: max(x, 0) or max(x, -inf).  As `if (relu)` the two paths left their results in different
+            // registers and every quad paid 24 moves to join them (ISA), on top of the branch
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        o[a][b] = make_float4(fmaxf(o[a][b].x, 0.0f), fmaxf(o[a][b].y, 0.0f), fmaxf(o[a][b].z, 0.0f), fmaxf(o[a][b].w, 0.0f));
-            }
+                for (int b = 0; b < 2; ++b)
+                    o[a][b] = make_float4(fmaxf(o[a][b].x, act_lo), fmaxf(o[a][b].y, act_lo), fmaxf(o[a][b].z, act_lo), fmaxf(o[a][b].w, act_lo));
             if (!pool) {
                 float* __restrict__ d = q00 + 8 * q;
                 if (full || in00) *reinterpret_cast<float4*>(d) = o[0][0];
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(wino::kThreads, 1) void conv_wino_f32_kernel(
     zero_acc();
     int par = 0, c = 0;
 #if WINO_STAMPS
-    unsigned long long t_last = __builtin_readcyclecounter();
+    t_last = __builtin_readcyclecounter();
 #endif
     for (;;) {
         const bool is_last = c + 1 == cur.nc;

@@ -121,7 +121,8 @@ def main():
                     help="strong scaling (BASELINE configs[3]): a fixed total of N holograms per step, sharded over the ranks "
                          "(contiguous blocks), processed in micro-batches of --batch, one gather of each rank's block")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--cpu-sample", type=int, default=4, help="holograms in the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16,
+                    help="holograms per pass of the CPU baseline (0 = skip); 16 x (1 warm-up + 5 timed passes) is 10-15 s of host work at 256 x 256")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a hipGraph (torch.cuda.CUDAGraph) and time K replays; the per-kernel "

@@ -153,7 +153,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if args.graph and (world > 1 or args.total):
+    if args.graph and (dist_on or args.total):
         raise SystemExit("--graph captures one single-rank step: it cannot hold the gather of a multi-rank step or a --total pass")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -10,6 +10,7 @@ exposes one as the reference's logical ``(B,C,H,W)`` shape without a copy (chann
 from __future__ import annotations
 
 import math
+import os
 import threading
 
 import torch
@@ -427,8 +428,7 @@ def distance_head(mean, std, sd, eps: float = 1e-5):
 # angular spectrum
 # ---------------------------------------------------------------------------------------------
 # fields per launch group: keeps the two S x P complex64 intermediates inside the 256 MiB Infinity Cache
-import os as _os
-_ASM_CACHE_BUDGET = int(_os.environ.get("HOLO_ASM_GROUP_MB", "320")) << 20      # (the variable is a tuning knob for scripts/bench_asm.py)
+_ASM_CACHE_BUDGET = int(os.environ.get("HOLO_ASM_GROUP_MB", "320")) << 20      # (the variable is a tuning knob for scripts/bench_asm.py)
 _ASM_KEEP_WORKSPACE = []      # diagnostics: a non-empty list receives the workspace tensor of the last call
 
 

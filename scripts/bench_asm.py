@@ -64,19 +64,6 @@ if args.check:
     amp, ph = amp_s, ph_s
     same = bool((a_e == a_e[:1]).all() and (p_e == p_e[:1]).all())
     print(f"check B={b} S={s} dist={args.dist}: max rel err vs oracle {worst:.2e}; identical fields give identical outputs: {same}", flush=True)
-    # control block of the dataflow kernel (csrc/asm_propagate.hip FusedCtl, behind the 3 * 4096 * 8 B of generic tables)
-    from style_transfer_based_holographic_imaging_amd import ops
-    ops._ASM_KEEP_WORKSPACE[:] = [None]
-    call()
-    torch.cuda.synchronize()
-    ws = ops._ASM_KEEP_WORKSPACE[0]
-    ops._ASM_KEEP_WORKSPACE.clear()
-    p_side = 2 * s
-    if ws is not None and 32 <= p_side <= 1024:
-        ctl = ws[3 * 4096 * 8: 3 * 4096 * 8 + 64 + 512].view(torch.int32).cpu().tolist()
-        tick = [ctl[16 + 16 * x] for x in range(8)]
-        nloc = [ctl[16 + 16 * x + 1] - 1 for x in range(8)]
-        print(f"  ctl: next_field {ctl[0]} error {ctl[1]} tickets/XCD {tick} local fields/XCD {nloc}", flush=True)
 
 for _ in range(5):
     call()

@@ -133,19 +133,6 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str = 
     return out
 
 
-# opt-in side builds that are kept alive by tests (never loaded unless HOLO_HIP_LIB points at them)
-VARIANTS = {
-    # the XCD-resident dataflow propagator (csrc/asm_propagate.hip, HOLO_ASM_FUSED): measured slower than the three-kernel
-    # path, kept parity-green as an experiment
-    "dataflow": (("-DHOLO_ASM_FUSED=1",), os.path.join(HERE, "libholo_hip_dataflow.so")),
-}
-
-
-def build_variant(name: str, force: bool = False, verbose: bool = True):
-    flags, out = VARIANTS[name]
-    return build(force=force, verbose=verbose, extra_flags=flags, out=out)
-
-
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(OUT)

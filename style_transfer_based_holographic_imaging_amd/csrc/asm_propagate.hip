@@ -907,509 +907,6 @@ __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_
     }
 }
 
-// ================================================================================================================
-// XCD-resident dataflow kernel (32 <= P <= 1024): ONE persistent launch runs all three stages of every field, and a field
-// never leaves the XCD that claimed it, so its intermediates T / U are exchanged through that XCD's 4 MiB L2 instead of HBM.
-//
-//   * Work is a per-XCD ticket stream.  A block reads its XCD from the hardware (HW_REG_XCC_ID — nothing is assumed about
-//     block -> XCD placement) and pops tickets from that XCD's counter.  Ticket t of an XCD = task r = t % NT of iteration
-//     it = t / NT, where an iteration is  [ A(it): n1 row tiles | B(it-1): n2 * D column tasks | C(it-2): n3 * D row tiles ]
-//     of the XCD's LOCAL fields it, it-1, it-2 — a software pipeline three fields deep.  Local field j is bound to a real
-//     field by the block that pops A(j)'s first ticket (one atomicAdd on a global counter, published in claim[xcc][j]; claims
-//     of one XCD are made in order, so its real fields form a prefix j = 0 .. n-1).  Fields are claimed by XCDs that have
-//     running blocks only, so any placement — even an XCD without blocks — completes.
-//   * A = pack + replicate-pad + row FFT of 16 rows, stored transposed into T slot (xcc, j % NSLOT);
-//     B = 16 columns: load, column FFT, H (table), column IFFT, store — IN PLACE for a single distance (U = the T slot),
-//         into the U slab of (field, distance) for a sweep;
-//     C = 16 rows of one output: transposed load, row IFFT, crop, abs / angle | intensity | complex.
-//   * Dependencies are completion counters per (XCD, local field): B(j) waits for n1 A tasks, C(j) for n2 * D B tasks, A(j)
-//     for the tasks that last used its slot (local field j - NSLOT).  Tickets are popped in an order in which every task's
-//     producers precede it, and a popped task is executed at once by a resident block that waits for nothing else, so
-//     every wait ends (induction over the ticket order) whatever the number of resident blocks.  Every spin loop is capped
-//     all the same: a block that exhausts the cap raises ctl->error and leaves, the launch ends instead of hanging.
-//   * Visibility: all tasks of a field run on ONE XCD, whose L2 is the coherence point of its CUs.  Producers: plain stores
-//     (the vector L1 is write-through) -> every wave s_waitcnt vmcnt(0) -> block barrier -> one agent-scope atomic add on the
-//     counter.  Consumers: one lane polls the counter with device-scope (sc1) loads -> block barrier -> EVERY load of T / U
-//     is a device-scope (sc1) load, which bypasses the CU's vector L1 (a slot's previous contents may still sit there) and
-//     is served by the XCD's L2.  Nothing crosses XCDs inside the launch: inputs and H tables come from earlier launches,
-//     outputs are consumed by later ones.
-//   * A tiny prologue launch zeroes the control block and fills the transfer-function tables.
-// ================================================================================================================
-// MEASURED (round 3, 64 fields x 256^2, tests/diagnostics + scripts/asm_trace.py): correct (3e-7 of the oracle, fields spread
-// 6-9 per XCD by the claims) but SLOWER than the three-kernel path, 150-190 us against 86 us per call: a task takes 7-12 us
-// (16-wave blocks in lockstep, two per CU), the scheduler's polls add 3-7 us per task and the block slots are busy 55 % of
-// the time; even fully busy the tasks add up to 76 us, because the propagator's floor is VECTOR-ALU ISSUE, not memory:
-// ~47 us of v_pk / transcendental work per call chip-wide, which moving T / U from HBM to the L2
-// does not touch.  Kept as an opt-in side build (-DHOLO_ASM_FUSED=1; tests/test_hip_propagator.py builds and checks it).
-#ifndef HOLO_ASM_FUSED
-#define HOLO_ASM_FUSED 0
-#endif
-#ifndef HOLO_ASM_NSLOT
-#define HOLO_ASM_NSLOT 4   // T slots per XCD: 3 = the pipeline's depth (A(j) then waits for the iteration just before it), 4 = one spare
-#endif
-#ifndef HOLO_ASM_TRACE
-#define HOLO_ASM_TRACE 0       // side builds only: every executed task leaves a 32-byte record (100 MHz real-time stamps) behind the workspace
-#endif
-constexpr size_t kTraceRecords = 1u << 16;
-#ifndef HOLO_ASM_FUSED_BPC
-#define HOLO_ASM_FUSED_BPC 0   // A/B knob: cap on resident blocks per CU (0 = what LDS and the wave limit allow)
-#endif
-constexpr int kXcc = 8;
-constexpr int kNSlot = HOLO_ASM_NSLOT;
-constexpr unsigned kClaimNone = 0x7fffffffu;
-#ifndef HOLO_ASM_SPIN_CAP
-#define HOLO_ASM_SPIN_CAP (1u << 20)          // polls of ~1 us: a second, far beyond any real wait
-#endif
-constexpr unsigned kSpinCap = HOLO_ASM_SPIN_CAP;
-
-struct FusedCtl {
-    unsigned next_field;          // global claim counter
-    unsigned error;               // a spin cap was hit (the results of the call are then incomplete); sticky: every wait gives up
-    unsigned pad0[14];
-    unsigned ticket[kXcc][16];    // per-XCD: [0] ticket counter, [1] 1 + number of real local fields once a claim has come back
-                                  // empty (0 = not known yet); one 64-byte line each
-    // followed by unsigned claim[kXcc][F], done_a[kXcc][F], done_b[kXcc][F], done_c[kXcc][F]
-};
-__host__ __device__ inline size_t fused_ctl_words(int n_fields) { return sizeof(FusedCtl) / 4 + (size_t)4 * kXcc * (size_t)n_fields; }
-__host__ __device__ inline size_t fused_ctl_bytes(int n_fields) { return (fused_ctl_words(n_fields) * 4 + 255) & ~(size_t)255; }
-
-template <int P>
-struct FusedCfg {
-    using R = RowTCfg<P>;
-    static constexpr int G = R::G, E = R::E, THREADS = R::THREADS, PITCH = R::PITCH;
-    static constexpr int CW = THREADS / G;            // 16 columns per B task, one per G lanes
-    static constexpr bool SYM = fft_plan_symmetric<P>();
-    static constexpr int TWF = tw_entries_fwd<P>(), TWI = SYM ? 0 : tw_entries_inv<P>();
-    static constexpr size_t LDS = (size_t)(TWF + TWI + R::BUF) * sizeof(float2);
-    static constexpr int BPC_LDS = (int)((160 * 1024 - 256) / LDS), BPC_THR = 2048 / THREADS;
-    static constexpr int BPC0 = BPC_LDS < BPC_THR ? BPC_LDS : BPC_THR;
-    static constexpr int BPC1 = BPC0 < 1 ? 1 : (BPC0 > 4 ? 4 : BPC0);
-    static constexpr int BPC = (HOLO_ASM_FUSED_BPC > 0 && HOLO_ASM_FUSED_BPC < BPC1) ? HOLO_ASM_FUSED_BPC : BPC1;
-    static constexpr int WAVES_PER_SIMD = (BPC * THREADS + 255) / 256;
-    static_assert(P % CW == 0 && CW == kTileRows, "column tasks tile the transform side");
-};
-
-__device__ __forceinline__ unsigned hw_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }   // hwreg(HW_REG_XCC_ID, 0, 4)
-
-// device-scope loads: bypass this CU's vector L1, served by the XCD's L2
-__device__ __forceinline__ v2f ld_dev(const v2f* p) {
-    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-    return __builtin_bit_cast(v2f, u);
-}
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_dev_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16);   // aux bit 4 = sc1 on gfx94x / gfx950
-    return __builtin_bit_cast(float4, v);
-}
-__device__ __forceinline__ unsigned ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// capped polls; a raised error flag ends every wait of the launch at once
-__device__ __forceinline__ bool spin_ge(const unsigned* p, unsigned want, const unsigned* err) {
-    for (unsigned n = 0; n < kSpinCap; ++n) {
-        if (ld_flag(p) >= want) return true;
-        if ((n & 255u) == 255u && ld_flag(err) != 0u) return false;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    return false;
-}
-// binding of local field j: claim[j] once published, or "none" as soon as the XCD's field count is known and <= j (the
-// block that would have published claim[j] may have left already: it only leaves after that count is known)
-__device__ __forceinline__ bool spin_claim(const unsigned* claim_j, const unsigned* end1, int j, const unsigned* err, unsigned* code) {
-    for (unsigned n = 0; n < kSpinCap; ++n) {
-        const unsigned c = ld_flag(claim_j);
-        if (c != 0u) { *code = c; return true; }
-        const unsigned e = ld_flag(end1);
-        if (e != 0u && (unsigned)j >= e - 1u) { *code = kClaimNone; return true; }
-        if ((n & 255u) == 255u && ld_flag(err) != 0u) return false;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    return false;
-}
-
-// prologue: transfer-function tables (blocks [0, tab_blocks), see asm_rows_fwd_t_kernel) + zeroed control block
-template <int P>
-__global__ __launch_bounds__(256) void asm_fused_prologue_kernel(unsigned* __restrict__ ctl, int ctl_words, int tab_blocks,
-                                                                 v2f* __restrict__ htab, const double* __restrict__ phase_const,
-                                                                 int n_out, double inv_ppx, double lam2, double lamb) {
-    const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= tab_blocks) {
-        const int i = ((int)blockIdx.x - tab_blocks) * 256 + tid;
-        if (i < ctl_words) ctl[i] = 0u;
-        return;
-    }
-    constexpr int HN = P / 2 + 1;
-    __shared__ double s_pc[kHSlots];
-    __shared__ int s_dup[kHSlots];
-    const int slots = n_out < kHSlots ? n_out : kHSlots;
-    if (tid < kHSlots) {
-        s_pc[tid] = phase_const[tid < slots ? tid : 0];
-        s_dup[tid] = 0;
-    }
-    __syncthreads();
-    for (int q = tid; q < kHSlots * kHSlots; q += 256) {
-        const int sl = q / kHSlots, g = q % kHSlots;
-        if (g < sl && sl < slots && s_pc[g] == s_pc[sl]) s_dup[sl] = 1;   // benign race: every writer stores 1
-    }
-    __syncthreads();
-    const int i = (int)blockIdx.x * 256 + tid;
-    if (i >= (int)htab_elems<P>()) return;
-    const int akx = i / HN, aky = i % HN;
-    const double fx = (double)akx * inv_ppx, fy = (double)aky * inv_ppx;
-    const double f2 = fx * fx + fy * fy;
-    for (int slot = 0; slot < slots; ++slot)
-        if (!s_dup[slot]) htab[(size_t)slot * htab_elems<P>() + i] = transfer_value(f2, lam2, s_pc[slot] / lamb);
-}
-
-struct FusedArgs {
-    const float *in0, *in1;
-    int in_mode;
-    long s0, s1;
-    float phase_scale;
-    float *out0, *out1;
-    int out_mode;
-    long os0, os1;
-    float scale;
-    const double* phase_const;
-    int n_fields, n_dist;
-    double inv_ppx, lam2, lamb;
-    v2f* tslots;          // [kXcc][slots_per_xcc] slabs of S x P complex64, transposed [kx][y]
-    v2f* ubuf;            // [n_fields * n_dist] slabs, or nullptr: single distance, U in place in the T slot
-    const v2f* htab;      // transfer-function tables or nullptr
-    unsigned* ctl;
-    int slots_per_xcc;
-    unsigned* trace;      // HOLO_ASM_TRACE builds: [0] record counter, then records of 8 words
-};
-
-// ---- task A: 16 rows of field f: pack, pad, row FFT, transposed store ------------------------------------------------
-template <int P, bool PAD>
-__device__ __forceinline__ void fused_task_rows_fwd(const FusedArgs& a, int f, int y0, v2f* __restrict__ tslab,
-                                                    const v2f* __restrict__ tw, v2f* __restrict__ buf, int tid) {
-    using C = FusedCfg<P>;
-    constexpr int S = PAD ? P / 2 : P;
-    constexpr int G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
-    constexpr int R1 = fft_radix<P, -1>(0);
-    constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);
-    const int seq = tid / G, t = tid % G;
-    v2f* my = buf + seq * PITCH;
-    v2f v[E];
-    {
-        const int y = y0 + seq;
-        const long base0 = (long)f * a.s0 + (long)y * S, base1 = (long)f * a.s1 + (long)y * S;
-        constexpr bool ONE_BFLY = (E == R1) && (G <= 64);
-        v2f edge0 = {0.f, 0.f}, edge1 = edge0;
-        if (PAD && !ONE_BFLY) {
-            edge0 = load_field(a.in0, a.in1, a.in_mode, base0, base1, a.phase_scale);
-            edge1 = load_field(a.in0, a.in1, a.in_mode, base0 + S - 1, base1 + S - 1, a.phase_scale);
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int r = e % R1;
-            const bool left = PAD && (r + 1) * 4 <= R1;
-            const bool right = PAD && r * 4 >= 3 * R1;
-            if (!left && !right) {
-                const int i = fft_elem_index<P, G, R1>(t, e);
-                const int col = PAD ? i - S / 2 : i;
-                v[e] = load_field(a.in0, a.in1, a.in_mode, base0 + col, base1 + col, a.phase_scale);
-            }
-        }
-        if (PAD && ONE_BFLY) {
-            const v2f lo = v[R1 / 4], hi = v[3 * R1 / 4 - 1];
-            edge0 = v2f{__shfl(lo.x, 0, G), __shfl(lo.y, 0, G)};
-            edge1 = v2f{__shfl(hi.x, G - 1, G), __shfl(hi.y, G - 1, G)};
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int r = e % R1;
-            if (PAD && (r + 1) * 4 <= R1) v[e] = edge0;
-            if (PAD && r * 4 >= 3 * R1) v[e] = edge1;
-        }
-    }
-    fft_run<P, G, -1>(v, my, tw, t);
-    __syncthreads();  // every row is done with its FFT buffer: the tile aliases them
-#pragma unroll
-    for (int e = 0; e < E; ++e) buf[fft_elem_index<P, G, RL>(t, e) * kTilePitch + seq] = v[e];
-    __syncthreads();
-    v2f* dst = tslab + y0;   // T^T[kx][y0 .. y0+15]: one 128-B run per kx, 16 B per thread
-    for (int q = tid; q < P * (kTileRows / 2); q += THREADS) {
-        const int kx = q / (kTileRows / 2), j = q % (kTileRows / 2);
-        const v2f p0 = buf[kx * kTilePitch + 2 * j], p1 = buf[kx * kTilePitch + 2 * j + 1];
-        *reinterpret_cast<float4*>(dst + (long)kx * S + 2 * j) = make_float4(p0.x, p0.y, p1.x, p1.y);
-    }
-}
-
-// ---- task B: 16 columns of one (field, distance): column FFT . H . column IFFT ----------------------------------------
-template <int P, bool PAD>
-__device__ __forceinline__ void fused_task_cols(const FusedArgs& a, int fo, int kx0, const v2f* __restrict__ tslab,
-                                                v2f* __restrict__ uslab, const v2f* __restrict__ twf,
-                                                const v2f* __restrict__ twi, v2f* __restrict__ buf, int tid) {
-    using C = FusedCfg<P>;
-    constexpr int S = PAD ? P / 2 : P;
-    constexpr int G = C::G, E = C::E, PITCH = C::PITCH;
-    constexpr int R1 = fft_radix<P, -1>(0);
-    constexpr int RL = fft_radix<P, -1>(FftPlan<P>::n - 1);  // forward's last = inverse's first radix
-    static_assert(fft_radix<P, +1>(0) == RL && fft_radix<P, +1>(FftPlan<P>::n - 1) == R1, "plan symmetry");
-    const int col = tid / G, t = tid % G;
-    const int kx = kx0 + col;
-    v2f* my = buf + col * PITCH;
-    // every wave finds the table slot of this output field itself (all 64 lanes are active here)
-    const int uid = a.htab != nullptr ? htab_uid_wave(a.phase_const, fo, tid & 63) : -1;
-    const v2f* src = tslab + (long)kx * S;
-    v2f v[E];
-    {
-        v2f edge0 = {0.f, 0.f}, edge1 = edge0;
-        if (PAD) {
-            edge0 = ld_dev(src);
-            edge1 = ld_dev(src + S - 1);
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int r = e % R1;
-            const bool left = PAD && (r + 1) * 4 <= R1;
-            const bool right = PAD && r * 4 >= 3 * R1;
-            if (left) v[e] = edge0;
-            else if (right) v[e] = edge1;
-            else {
-                const int i = fft_elem_index<P, G, R1>(t, e);
-                v[e] = ld_dev(src + (PAD ? i - S / 2 : i));
-            }
-        }
-    }
-    fft_run<P, G, -1>(v, my, twf, t);   // spectrum in registers at ky = fft_elem_index<P,G,RL>(t,e)
-    if (uid >= 0) {
-        const v2f* __restrict__ hcol = a.htab + (size_t)uid * htab_elems<P>() + (size_t)(kx <= P / 2 ? kx : P - kx) * (P / 2 + 1);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int ky = fft_elem_index<P, G, RL>(t, e);
-            v[e] = cmul(v[e], hcol[ky <= P / 2 ? ky : P - ky]);
-        }
-    } else {
-        // no table slot (more than kHSlots distinct distances in the call): one value per (column, |ky|), shared through LDS
-        fft_sync<G>();
-        {
-            const double c_over_l = a.phase_const[fo] / a.lamb;
-            const double fx = (double)(kx <= P / 2 ? kx : P - kx) * a.inv_ppx;
-            const double fx2 = fx * fx;
-            for (int m = t; m <= P / 2; m += G) {
-                const double fy = (double)m * a.inv_ppx;
-                my[m] = transfer_value(fx2 + fy * fy, a.lam2, c_over_l);
-            }
-        }
-        fft_sync<G>();
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int ky = fft_elem_index<P, G, RL>(t, e);
-            v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
-        }
-    }
-    fft_run<P, G, +1>(v, my, twi, t);
-    v2f* dst = uslab + (long)kx * S;   // keep the S centre rows: contiguous runs of G values per register slot
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int r = e % R1;
-        if (PAD && ((r + 1) * 4 <= R1 || r * 4 >= 3 * R1)) continue;
-        const int i = fft_elem_index<P, G, R1>(t, e);
-        dst[PAD ? i - S / 2 : i] = v[e];
-    }
-}
-
-// ---- task C: 16 rows of output field fo: transposed load, row IFFT, crop, epilogue -------------------------------------
-template <int P, bool PAD>
-__device__ __forceinline__ void fused_task_rows_inv(const FusedArgs& a, int fo, int y0, const v2f* __restrict__ uslab,
-                                                    const v2f* __restrict__ tw, v2f* __restrict__ buf, int tid) {
-    using C = FusedCfg<P>;
-    constexpr int S = PAD ? P / 2 : P;
-    constexpr int G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
-    constexpr int R1 = fft_radix<P, +1>(0);
-    constexpr int RL = fft_radix<P, +1>(FftPlan<P>::n - 1);
-    constexpr int LD = P * (kTileRows / 2) / THREADS;   // 16-byte pieces of a tile per thread (= E/2)
-    static_assert(LD * THREADS == P * (kTileRows / 2), "the tile divides evenly over the block");
-    const int seq = tid / G, t = tid % G;
-    v2f* my = buf + seq * PITCH;
-    {
-        // the slab base is block-uniform: keep the resource in scalar registers
-        const unsigned long long base = reinterpret_cast<unsigned long long>(uslab);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base), hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)((size_t)S * P * sizeof(float2)), 0x00020000);
-        float4 pre[LD];
-#pragma unroll
-        for (int l = 0; l < LD; ++l) {
-            const int q = tid + l * THREADS;
-            const unsigned off = (unsigned)(((q / (kTileRows / 2)) * S + y0 + 2 * (q % (kTileRows / 2))) * (int)sizeof(float2));
-            pre[l] = ld_dev_b128(rsrc, off);
-        }
-#pragma unroll
-        for (int l = 0; l < LD; ++l) {   // U^T[kx][y0 .. y0+15] -> tile[kx][row]
-            const int q = tid + l * THREADS;
-            const int kx = q / (kTileRows / 2), j = q % (kTileRows / 2);
-            buf[kx * kTilePitch + 2 * j] = v2f{pre[l].x, pre[l].y};
-            buf[kx * kTilePitch + 2 * j + 1] = v2f{pre[l].z, pre[l].w};
-        }
-    }
-    __syncthreads();
-    v2f v[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = buf[fft_elem_index<P, G, R1>(t, e) * kTilePitch + seq];
-    __syncthreads();  // the tile is consumed: its space becomes the rows' FFT buffers
-    fft_run<P, G, +1>(v, my, tw, t);
-    const int y = y0 + seq;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int r = e % RL;
-        if (PAD && ((r + 1) * 4 <= RL || r * 4 >= 3 * RL)) continue;   // centre crop (Angular_Spectrum_Method.py:34)
-        const int i = fft_elem_index<P, G, RL>(t, e);
-        const int x = PAD ? i - S / 2 : i;
-        const v2f o = v[e] * a.scale;
-        const long pix = (long)y * S + x;
-        if (a.out_mode == HOLO_ASM_OUT_AMP_PHASE) {
-            a.out0[(long)fo * a.os0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
-            a.out1[(long)fo * a.os1 + pix] = atan2_poly(o.y, o.x);
-        } else if (a.out_mode == HOLO_ASM_OUT_INTENSITY) {
-            const float am = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
-            a.out0[(long)fo * a.os0 + pix] = am * am;
-        } else {
-            reinterpret_cast<v2f*>(a.out0)[(long)fo * a.os0 + pix] = o;
-        }
-    }
-}
-
-template <int P, bool PAD>
-__global__ __launch_bounds__(FusedCfg<P>::THREADS, FusedCfg<P>::WAVES_PER_SIMD) void asm_fused_kernel(const FusedArgs a) {
-    using C = FusedCfg<P>;
-    constexpr int S = PAD ? P / 2 : P;
-    constexpr int THREADS = C::THREADS;
-    constexpr int N1 = S / kTileRows;          // A tasks per field
-    constexpr int N2 = P / C::CW;              // B tasks per (field, distance)
-    constexpr int N3 = S / kTileRows;          // C tasks per (field, distance)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    v2f* twf = reinterpret_cast<v2f*>(smem_raw);
-    v2f* twi = C::SYM ? twf : twf + C::TWF;
-    v2f* buf = twf + C::TWF + C::TWI;
-    __shared__ int s_task[6];                  // status, phase, tile, field, local field, next ticket
-#if HOLO_ASM_TRACE
-    __shared__ unsigned long long s_stamp[4];
-#endif
-
-    const int tid = threadIdx.x;
-    const int F = a.n_fields, D = a.n_dist;
-    const int nb = N2 * D, nc = N3 * D, NT = N1 + nb + nc;
-    const unsigned xcc = hw_xcc_id();
-    FusedCtl* ctl = reinterpret_cast<FusedCtl*>(a.ctl);
-    unsigned* claim = a.ctl + sizeof(FusedCtl) / 4 + (size_t)xcc * F;
-    unsigned* done_a = claim + (size_t)kXcc * F;
-    unsigned* done_b = done_a + (size_t)kXcc * F;
-    unsigned* done_c = done_b + (size_t)kXcc * F;
-    const size_t slab = (size_t)S * P;
-
-    fft_fill_twiddles<P, -1>(twf, tid, THREADS);
-    if (!C::SYM) fft_fill_twiddles<P, +1>(twi, tid, THREADS);
-    if (tid == 0) s_task[5] = (int)__hip_atomic_fetch_add(&ctl->ticket[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-
-    // an XCD hands out at most (F + 3) * NT tickets before every block has met its exit ticket: a hard bound on the loop
-    for (long turn = 0, max_turns = ((long)F + 4) * NT + 16;; ++turn) {
-        if (turn >= max_turns) {
-            if (tid == 0) __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (tid == 0) {
-            // scheduler: decode the ticket, bind the local field, wait for the task's producers; the next ticket is
-            // requested now and read after the task
-            const int tk = s_task[5];
-#if HOLO_ASM_TRACE
-            s_stamp[0] = __builtin_amdgcn_s_memrealtime();
-            s_stamp[3] = (unsigned long long)tk;
-#endif
-            const unsigned nxt_req = __hip_atomic_fetch_add(&ctl->ticket[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int it = tk / NT, r = tk % NT;
-            int phase, j, tile;
-            if (r < N1) { phase = 0; j = it; tile = r; }
-            else if (r < N1 + nb) { phase = 1; j = it - 1; tile = r - N1; }
-            else { phase = 2; j = it - 2; tile = r - N1 - nb; }
-            int status = 0, f = 0;   // 0 run, 1 skip, 2 exit, 3 error
-            if (j < 0) status = 1;
-            else {
-                unsigned code = kClaimNone;
-                bool ok = true;
-                const unsigned* err = &ctl->error;
-                unsigned* end1 = &ctl->ticket[xcc][1];
-                if (j < F) {
-                    if (phase == 0 && tile == 0) {
-                        // claims of one XCD are made in order: its real fields form a prefix of the local indices
-                        unsigned prev = 1u;
-                        if (j > 0) ok = spin_claim(&claim[j - 1], end1, j - 1, err, &prev);
-                        if (ok && prev != kClaimNone) {
-                            const unsigned got = __hip_atomic_fetch_add(&ctl->next_field, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            code = got < (unsigned)F ? got + 1u : kClaimNone;
-                            if (code == kClaimNone) __hip_atomic_store(end1, (unsigned)j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        __hip_atomic_store(&claim[j], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        ok = spin_claim(&claim[j], end1, j, err, &code);
-                    }
-                }
-                if (!ok) status = 3;
-                else if (code == kClaimNone) status = phase == 2 ? 2 : 1;
-                else {
-                    f = (int)code - 1;
-                    if (phase == 0) {
-                        if (j >= a.slots_per_xcc)   // the slot's previous field must have left it
-                            ok = a.ubuf ? spin_ge(&done_b[j - a.slots_per_xcc], (unsigned)nb, err) : spin_ge(&done_c[j - a.slots_per_xcc], (unsigned)nc, err);
-                    } else if (phase == 1) ok = spin_ge(&done_a[j], (unsigned)N1, err);
-                    else ok = spin_ge(&done_b[j], (unsigned)nb, err);
-                    if (!ok) status = 3;
-                }
-            }
-            if (status == 3) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_task[0] = status; s_task[1] = phase; s_task[2] = tile; s_task[3] = f; s_task[4] = j;
-            s_task[5] = (int)nxt_req;
-#if HOLO_ASM_TRACE
-            s_stamp[1] = __builtin_amdgcn_s_memrealtime();
-#endif
-        }
-        __syncthreads();
-        const int status = s_task[0], phase = s_task[1], tile = s_task[2], f = s_task[3], j = s_task[4];
-        if (status >= 2) return;
-        if (status == 0) {
-            v2f* tslab = a.tslots + ((size_t)xcc * a.slots_per_xcc + (size_t)(j % a.slots_per_xcc)) * slab;
-            unsigned* done = nullptr;
-            if (phase == 0) {
-                fused_task_rows_fwd<P, PAD>(a, f, tile * kTileRows, tslab, twf, buf, tid);
-                done = &done_a[j];
-            } else if (phase == 1) {
-                const int grp = tile / D, d = tile % D;     // consecutive tickets re-read the same T columns
-                v2f* uslab = a.ubuf ? a.ubuf + ((size_t)f * D + d) * slab : tslab;
-                fused_task_cols<P, PAD>(a, f * D + d, grp * C::CW, tslab, uslab, twf, twi, buf, tid);
-                done = &done_b[j];
-            } else {
-                const int d = tile / N3, ty = tile % N3;
-                const v2f* uslab = a.ubuf ? a.ubuf + ((size_t)f * D + d) * slab : tslab;
-                fused_task_rows_inv<P, PAD>(a, f * D + d, ty * kTileRows, uslab, twi, buf, tid);
-                done = &done_c[j];
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
-            __syncthreads();
-            if (tid == 0) {
-#if HOLO_ASM_TRACE
-                const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
-#endif
-                __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if HOLO_ASM_TRACE
-                const unsigned rec = __hip_atomic_fetch_add(&a.trace[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (rec < kTraceRecords) {
-                    unsigned* w = a.trace + 8 + (size_t)rec * 8;
-                    w[0] = xcc | (blockIdx.x << 8); w[1] = (unsigned)s_stamp[3]; w[2] = (unsigned)phase | ((unsigned)j << 8) | ((unsigned)tile << 16);
-                    w[3] = (unsigned)s_stamp[0]; w[4] = (unsigned)s_stamp[1]; w[5] = (unsigned)t2;
-                    w[6] = (unsigned)__builtin_amdgcn_s_memrealtime(); w[7] = (unsigned)f;
-                }
-#endif
-            }
-        } else {
-            __syncthreads();   // s_task is rewritten next
-        }
-    }
-}
-
 // Phase constants c of theta = c * G for float32 distances, with the reference's rounding chain in ONE launch
 // (Forward_model.py:18 + Angular_Spectrum_Method.py:29):
 //   c = double( fl32( fl32(2 pi) * fl32( fl32( fl32(d + add) * mul ) * fl32(1e-3) ) ) )
@@ -1443,9 +940,6 @@ struct AsmArgs {
     double* f2;
     float2 *tbuf, *ubuf;
     float2* htab;   // transfer-function tables (transposed-layout path), or nullptr
-    unsigned* ctl;  // control block of the dataflow kernel (fused path)
-    int slots_per_xcc;
-    unsigned* trace;
     hipStream_t stream;
     int ablate;   // -DHOLO_DEBUG builds only (HOLO_ASM_ABLATE): 1 = skip H evaluation, 2 = skip the FFT passes; 0 in the shipped build
 };
@@ -1547,51 +1041,10 @@ static int launch_asm_t(const AsmArgs& a) {
     return check_launch("holo_asm_propagate");
 }
 
-// XCD-resident dataflow path (32 <= P <= 1024): a prologue (control block + tables) and ONE persistent launch
-template <int P, bool PAD>
-static int launch_asm_fused(const AsmArgs& a) {
-    using C = FusedCfg<P>;
-    constexpr int S = PAD ? P / 2 : P;
-    static DeviceOnce attr_once;  // per device, published after the attribute is set
-    attr_once.run([] {
-        if (C::LDS > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_fused_kernel<P, PAD>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
-    });
-    const int n_out = a.n_fields * a.n_dist;
-    const int tab_blocks = a.htab != nullptr ? (int)((htab_elems<P>() + 255) / 256) : 0;
-    const int ctl_words = (int)fused_ctl_words(a.n_fields);
-    hipLaunchKernelGGL((asm_fused_prologue_kernel<P>), dim3((unsigned)(tab_blocks + (ctl_words + 255) / 256)), dim3(256), 0, a.stream,
-                       a.ctl, ctl_words, tab_blocks, reinterpret_cast<v2f*>(a.htab), a.phase_const, n_out, 1.0 / a.ppx, a.lam2, a.lamb);
-    FusedArgs fa;
-    fa.in0 = a.in0; fa.in1 = a.in1; fa.in_mode = a.in_mode; fa.s0 = a.s0; fa.s1 = a.s1; fa.phase_scale = a.phase_scale;
-    fa.out0 = a.out0; fa.out1 = a.out1; fa.out_mode = a.out_mode; fa.os0 = a.os0; fa.os1 = a.os1;
-    fa.scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
-    fa.phase_const = a.phase_const; fa.n_fields = a.n_fields; fa.n_dist = a.n_dist;
-    fa.inv_ppx = 1.0 / a.ppx; fa.lam2 = a.lam2; fa.lamb = a.lamb;
-    fa.tslots = reinterpret_cast<v2f*>(a.tbuf);
-    fa.ubuf = a.n_dist > 1 ? reinterpret_cast<v2f*>(a.ubuf) : nullptr;
-    fa.htab = reinterpret_cast<const v2f*>(a.htab);
-    fa.ctl = a.ctl; fa.slots_per_xcc = a.slots_per_xcc;
-    fa.trace = a.trace;
-#if HOLO_ASM_TRACE
-    (void)hipMemsetAsync(a.trace, 0, 32, a.stream);
-#endif
-    const long tasks = (long)a.n_fields * (S / kTileRows + (long)a.n_dist * (P / C::CW + S / kTileRows));
-    const long resident = (long)device_cus() * C::BPC;
-    const unsigned grid = (unsigned)(tasks < resident ? tasks : resident);
-    hipLaunchKernelGGL((asm_fused_kernel<P, PAD>), dim3(grid), dim3(C::THREADS), C::LDS, a.stream, fa);
-    return check_launch("holo_asm_propagate");
-}
-
 template <int P>
 static int launch_asm_pad(const AsmArgs& a, bool pad) {
     if constexpr (P >= 32 && P <= 1024) {
-#if HOLO_ASM_FUSED
-        return pad ? launch_asm_fused<P, true>(a) : launch_asm_fused<P, false>(a);
-#else
         return pad ? launch_asm_t<P, true>(a) : launch_asm_t<P, false>(a);
-#endif
     } else if constexpr (P == 16) {
         return pad ? launch_asm<P, true>(a) : launch_asm_t<P, false>(a);   // S = 8 rows cannot fill a 16-row tile
     } else {
@@ -1739,13 +1192,10 @@ constexpr size_t kTableBytes = 2 * kTwSlots * sizeof(float2) + kTwSlots * sizeof
 
 extern "C" {
 
-// Workspace layout.  Head: tables of the generic-size path.  Dataflow path (power-of-two transform side 32..1024): control
-// block, kXcc x min(NSLOT, n_fields) T slots, U slabs only for a sweep (a single distance runs in place in the T slot),
-// transfer-function tables.  Other paths: T (n_fields slabs), U (n_fields * n_dist slabs), tables where the path has them.
+// Workspace layout.  Head: tables of the generic-size path; then T (n_fields slabs), U (n_fields * n_dist slabs) and,
+// where the path has them (power-of-two transform side 32..1024), the transfer-function tables.
 struct AsmLayout {
-    bool fused;
-    int slots_per_xcc;
-    size_t ctl_off, t_off, u_off, htab_off, total;
+    size_t t_off, u_off, htab_off, total;
 };
 static AsmLayout asm_layout(int n_fields, int n_dist, int s, int zero_padding) {
     AsmLayout l;
@@ -1753,19 +1203,13 @@ static AsmLayout asm_layout(int n_fields, int n_dist, int s, int zero_padding) {
     const size_t slab = (size_t)s * p * sizeof(float2);
     const bool pow2 = (p & (p - 1)) == 0;
     const bool transposed = pow2 && p >= 32 && p <= 1024;
-    l.fused = transposed && HOLO_ASM_FUSED;
-    l.slots_per_xcc = n_fields < holo::kNSlot ? n_fields : holo::kNSlot;
     const size_t n_out = (size_t)n_fields * (size_t)n_dist;
     const size_t slots = n_out < (size_t)holo::kHSlots ? n_out : (size_t)holo::kHSlots;
     const size_t htab = transposed ? slots * (p / 2 + 1) * (p / 2 + 1) * sizeof(float2) : 0;
-    l.ctl_off = holo::kTableBytes;
-    l.t_off = l.ctl_off + (l.fused ? holo::fused_ctl_bytes(n_fields) : 0);
-    l.u_off = l.t_off + slab * (l.fused ? (size_t)holo::kXcc * l.slots_per_xcc : (size_t)n_fields);
-    l.htab_off = l.u_off + (l.fused && n_dist == 1 ? 0 : slab * n_out);
+    l.t_off = holo::kTableBytes;
+    l.u_off = l.t_off + slab * (size_t)n_fields;
+    l.htab_off = l.u_off + slab * n_out;
     l.total = l.htab_off + htab;
-#if HOLO_ASM_TRACE
-    l.total = ((l.total + 255) & ~(size_t)255) + (8 + 8 * holo::kTraceRecords) * sizeof(unsigned);
-#endif
     return l;
 }
 
@@ -1833,16 +1277,9 @@ int holo_asm_propagate(const void* in0, const void* in1, int in_mode, long in0_s
     a.f2 = reinterpret_cast<double*>(a.twi + kTwSlots);
     const AsmLayout lay = asm_layout(n_fields, n_dist, s, zero_padding);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
-    a.ctl = reinterpret_cast<unsigned*>(ws + lay.ctl_off);
-    a.slots_per_xcc = lay.slots_per_xcc;
     a.tbuf = reinterpret_cast<float2*>(ws + lay.t_off);
     a.ubuf = reinterpret_cast<float2*>(ws + lay.u_off);
     a.htab = lay.total > lay.htab_off ? reinterpret_cast<float2*>(ws + lay.htab_off) : nullptr;
-    a.trace = nullptr;
-#if HOLO_ASM_TRACE
-    a.trace = reinterpret_cast<unsigned*>(ws + lay.total - (8 + 8 * kTraceRecords) * sizeof(unsigned));
-    a.htab = (lay.total - (8 + 8 * kTraceRecords) * sizeof(unsigned)) > lay.htab_off + 256 ? reinterpret_cast<float2*>(ws + lay.htab_off) : nullptr;
-#endif
     a.stream = as_stream(stream);
     a.ablate = 0;
 #ifdef HOLO_DEBUG   // timing experiments only (wrong results): never read in the shipped build

@@ -429,7 +429,6 @@ def distance_head(mean, std, sd, eps: float = 1e-5):
 # ---------------------------------------------------------------------------------------------
 # fields per launch group: keeps the two S x P complex64 intermediates inside the 256 MiB Infinity Cache
 _ASM_CACHE_BUDGET = int(os.environ.get("HOLO_ASM_GROUP_MB", "320")) << 20      # (the variable is a tuning knob for scripts/bench_asm.py)
-_ASM_KEEP_WORKSPACE = []      # diagnostics: a non-empty list receives the workspace tensor of the last call
 
 
 def phase_constant(d, n_fields: int, device) -> torch.Tensor:
@@ -521,8 +520,6 @@ def asm_propagate(in0, in1, phase_c, s, zero_padding, wavelength, pixel_size, ph
     group = -(-n_fields // -(-n_fields // group))      # near-equal groups: 64 fields at 20 per group run as 4 x 16, not 20 + 20 + 20 + 4
     ws_bytes = lib.holo_asm_workspace_bytes(group, n_dist, s, int(bool(zero_padding)))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    if _ASM_KEEP_WORKSPACE:
-        _ASM_KEEP_WORKSPACE[:] = [ws]        # diagnostics (scripts/bench_asm.py --check reads the dataflow kernel's control block)
     esz_in = 8 if complex_in else 4
     esz_out = 8 if out_mode == _lib.ASM_OUT_COMPLEX else 4
     plane = s * s

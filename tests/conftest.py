@@ -18,8 +18,6 @@ def pytest_configure(config):
     from style_transfer_based_holographic_imaging_amd import build as _build
     if not os.environ.get("HOLO_HIP_LIB") and _build.needs_build():
         _build.build(verbose=False)
-        for name in _build.VARIANTS:
-            _build.build_variant(name, verbose=False)
 
 
 def rel_err(a, b):

@@ -286,31 +286,6 @@ def test_transfer_function_tables_dedupe_distances(hg, dev):
     assert cplx_rel(torch.polar(a_all, p_all), ref) < 1e-5
 
 
-@pytest.mark.parametrize("b,s,dist", [(9, 64, 1), (20, 128, 1), (3, 256, 1), (2, 128, 8), (2, 16, 1)])
-def test_dataflow_variant_stays_parity_green(b, s, dist):
-    """The opt-in XCD-resident dataflow propagator (-DHOLO_ASM_FUSED=1 side build, csrc/asm_propagate.hip): one persistent
-    launch, a field's three stages on ONE XCD, intermediates through that XCD's L2.  Slower than the shipped three-kernel
-    path, kept correct: own process with HOLO_HIP_LIB pointing at the side build; the script compares with
-    the oracle after repeated calls (slot reuse, warm caches), checks that identical fields give identical outputs, and
-    reads the kernel's control block (no wait gave up, every field was claimed)."""
-    import os
-    import re
-    import subprocess
-    import sys
-    from conftest import REPO
-    from style_transfer_based_holographic_imaging_amd import build
-    lib = build.build_variant("dataflow", verbose=False)
-    env = dict(os.environ, HOLO_HIP_LIB=lib, PYTHONUNBUFFERED="1")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "bench_asm.py"), str(b), str(s), "10", "--dist", str(dist), "--check"],
-                       cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    m = re.search(r"max rel err vs oracle ([0-9.eE+-]+); identical fields give identical outputs: (\w+)", r.stdout)
-    assert m and float(m.group(1)) < 1e-5 and m.group(2) == "True", r.stdout
-    c = re.search(r"ctl: next_field (\d+) error (\d+) .* local fields/XCD \[([-0-9, ]+)\]", r.stdout)
-    assert c and int(c.group(2)) == 0, r.stdout
-    assert sum(max(0, int(v)) for v in c.group(3).split(",")) == b          # every field claimed by exactly one XCD
-
-
 def test_phase_constants_kernel_reproduces_the_aten_rounding_chain(hg, dev):
     """holo_asm_phase_constants_f32 against the element-wise torch chain it replaces (Forward_model.py:18 then
     Angular_Spectrum_Method.py:29): bit-identical float64 constants for random distances, offsets and scales, per-sample,

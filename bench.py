@@ -86,13 +86,13 @@ def cpu_baseline(size, sds, style, sample, seed):
 PMC_PROFILE = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 
 
-def pmc_traffic(batch, size, dtype, distances):
+def pmc_traffic(batch, size, dtype, distances, single_rank_step=True):
     """HBM bytes (conv: per launch; propagator: per call) from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     over this same command (scripts/collect_pmc.py -> profiles/r03_pmc_traffic.json; FETCH_SIZE doubled per
     MI355X_MICROARCH.md §HBM).  Counters cannot be read from inside the process, so the numbers are only reported for the
     workload AND the library build they were collected on (the profile stores the library's source hash): anything else
     gives null rather than a stale figure."""
-    if (batch, size, dtype, distances) != (64, 256, "f32", 1) or not os.path.isfile(PMC_PROFILE):
+    if not single_rank_step or (batch, size, dtype, distances) != (64, 256, "f32", 1) or not os.path.isfile(PMC_PROFILE):
         return None, None, None
     from style_transfer_based_holographic_imaging_amd import _lib
     with open(PMC_PROFILE) as f:
@@ -121,6 +121,9 @@ def main():
                     help="strong scaling (BASELINE configs[3]): a fixed total of N holograms per step, sharded over the ranks "
                          "(contiguous blocks), processed in micro-batches of --batch, one gather of each rank's block")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dump-block", default="",
+                    help="with --total: rank 0 saves the gathered (N, 4*S*S+1) block of one extra pass AFTER the timed region "
+                         "(tests compare it across rank counts)")
     ap.add_argument("--cpu-sample", type=int, default=16,
                     help="holograms per pass of the CPU baseline (0 = skip); 16 x (1 warm-up + 5 timed passes) is 10-15 s of host work at 256 x 256")
     ap.add_argument("--no-events", action="store_true", help="do not record per-launch HIP events")
@@ -189,7 +192,11 @@ def main():
         del chunks, ph_j, d_j
         n_local = hi - lo
         d_style = torch.full((max(b, 1), 1, 1, 1), -0.2, device=dev)     # back-propagation: -distance_style (test_field_retrieval_mnist.py:126)
-        block = torch.empty((n_local, shard.packed_width(s)), dtype=torch.float32, device=dev)
+        # send buffer of the padded block size and (root) receive buffer, both kept for the whole job: a ragged pass
+        # copies and allocates nothing
+        rows_max = shard.block_rows(args.total, world)
+        block = torch.zeros((rows_max, shard.packed_width(s)), dtype=torch.float32, device=dev)
+        recv = torch.empty((world, rows_max, shard.packed_width(s)), dtype=torch.float32, device=dev) if (dist_on and rank == 0) else None
     else:
         seed = 1234 + rank
         ph = synth.synthetic_phase_objects(b, s, seed=seed).to(dev)
@@ -232,7 +239,7 @@ def main():
         with torch.no_grad():
             if pending:                      # the block buffer is reused: the previous pass's gather must have left it
                 pending.pop(0).wait()
-            pending.append(shard.sharded_pass(args.total, b, process, shard.packed_width(s), dev, async_op=True, block=block))
+            pending.append(shard.sharded_pass(args.total, b, process, shard.packed_width(s), dev, async_op=True, block=block, recv=recv))
         return last[0] if last else None
 
     step = step_strong if args.total else step_weak
@@ -283,25 +290,71 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gather_ms = None
+    if dist_on and args.distances == 1:
+        # the gather's own time, measured SEPARATELY after the timed region (in the steps it rides under the next
+        # step's kernels): three blocking gathers of one step's message between barriers, every rank joins, MAX over ranks
+        with torch.no_grad():
+            if args.total:
+                def one_gather():
+                    counts = [shard.shard_bounds(args.total, world, q)[1] - shard.shard_bounds(args.total, world, q)[0] for q in range(world)]
+                    shard.gather_to_root(block, counts, recv=recv)
+            else:
+                amp_g, p_g, d_g, af_g, pf_g = one_batch(content, d_style)
+                msg = shard.pack_outputs(amp_g, p_g, af_g, pf_g, d_g)
+
+                def one_gather():
+                    shard.gather_to_root(msg)
+        one_gather()
+        sync()
+        tg = time.perf_counter()
+        for _ in range(3):
+            one_gather()
+        sync()
+        tgt = torch.tensor([(time.perf_counter() - tg) / 3.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
+        gather_ms = round(float(tgt.item()) * 1e3, 3)
+
+    if args.total and args.dump_block:
+        step()                            # one extra pass, outside the timed region; every rank joins its gather
+        gathered = pending.pop(0).wait()
+        sync()
+        if rank == 0:
+            torch.save(gathered.cpu(), args.dump_block)
+
     if rank == 0:
         total = (args.total if args.total else b * world) * args.steps
         coll = {"nccl": "RCCL"}.get(backend, backend) if dist_on else "none (single rank)"
-        cfg_no = 3 if args.total else (2 if args.dtype == "bf16" else 1)
+        # which BASELINE config the run IS (exact match of its defining parameters), else the nearest one named as a variant
+        if args.total:
+            cfg = "BASELINE configs[3]" if (args.total, s, args.dtype) == (2048, 256, "f32") else "variant of BASELINE configs[3] (fixed total)"
+        elif args.distances > 1:
+            cfg = "BASELINE configs[4]" if (b, s, args.distances, args.style, args.dtype) == (32, 1024, 8, "red_blood_cell", "f32") else "variant of BASELINE configs[4] (multi-distance sweep)"
+        elif args.dtype == "bf16":
+            cfg = "BASELINE configs[2]" if (b, s) == (256, 512) else "variant of BASELINE configs[2] (bf16 convs)"
+        elif args.dtype == "f32":
+            cfg = "BASELINE configs[1]" if (b, s) == (64, 256) else "variant of BASELINE configs[1]"
+        else:
+            cfg = "opt-in f32s mode (no BASELINE config)"
         per_gpu = f"{args.total} holograms in all, contiguous blocks of {-(-args.total // world)} per GPU in micro-batches of {b}" if args.total else f"batch {b}/GPU"
         out = {
             "metric": "holograms/sec (256x256 complex field retrieval)" if s == 256 else f"holograms/sec ({s}x{s} complex field retrieval)",
             "value": round(total / elapsed, 2), "unit": "holograms/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong" if args.total else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{cfg_no}]: {per_gpu}, synthetic {s}x{s} holograms, "
+            "config": {"workload": f"{cfg}: {per_gpu}, synthetic {s}x{s} holograms, "
                                    f"{ {'f32': 'fp32', 'bf16': 'bf16 convs / fp32 FFT', 'f32s': 'convs on split-fp16 operands (hi + lo*2^-11, fp32 accumulate; NOT fp32 arithmetic) / fp32 FFT'}[args.dtype] }, VGG-AdaIN-decoder + "
                                    f"distance head + angular-spectrum back-propagation (P={2 * s}), seeded He-normal weights",
                        "batch_per_gpu": b, "size": s, "distances_per_field": args.distances, "style": args.style, "hipgraph": bool(args.graph), "conv_algo": args.conv_algo, "total_holograms": args.total or b * world,
                        "parallelism": f"batch-sharded x{world}, one {coll} gather per step" if dist_on else "single GPU"},
         }
+        if gather_ms is not None:
+            out["gather_ms"] = gather_ms
+            out["gather_note"] = (f"one blocking {coll} gather of a step's packed outputs to rank 0 with a barrier after it, timed "
+                                  "alone after the timed region (inside the steps it is asynchronous and overlaps the next step)")
         if timer is not None:
             summ = timer.summary()
-            traffic_conv, traffic_asm, traffic_src = pmc_traffic(b, s, args.dtype, args.distances)
+            traffic_conv, traffic_asm, traffic_src = pmc_traffic(b, s, args.dtype, args.distances, single_rank_step=(world == 1 and not args.total))
             wino = summ.get("holo_conv3x3_wino_f32")
             # the dominant kernel: the Winograd 3x3 kernel where it runs (fp32, large layers), else the implicit-GEMM kernel
             conv = [wino] if wino else [summ[k] for k in (f"holo_conv3x3_{args.dtype}", f"holo_convt2x2_{args.dtype}") if k in summ]

@@ -67,23 +67,32 @@ def micro_batches(lo: int, hi: int, micro_batch: int):
     return [tuple(lo + v for v in shard_bounds(n, pieces, i)) for i in range(pieces)]
 
 
+def block_rows(n_total: int, world: int) -> int:
+    """Rows of the largest rank block of a fixed-total job: the size every rank's send buffer is padded to."""
+    return -(-n_total // world)
+
+
 def sharded_pass(n_total: int, micro_batch: int, process, width: int, device, dtype=torch.float32, async_op: bool = False,
-                 block=None):
+                 block=None, recv=None):
     """One pass over a FIXED total of ``n_total`` holograms (strong scaling; BASELINE configs[3]: 2048 holograms over
     1/2/4/8 GPUs): this rank's contiguous block ``shard_bounds(n_total, world, rank)`` is processed in micro-batches —
     ``process(m0, m1, out_rows)`` handles GLOBAL holograms [m0, m1) and writes their packed outputs into ``out_rows``
     ((m1 - m0, width)) — and the block goes to rank 0 with ONE gather (ragged blocks allowed).  Returns what
-    ``gather_to_root`` returns.  No data-path collective besides that gather."""
+    ``gather_to_root`` returns.  No data-path collective besides that gather.
+
+    ``block``: a send buffer kept across passes, of ``block_rows(n_total, world)`` rows (the padded size: a ragged job then
+    gathers it as it stands, nothing is copied or allocated per pass) or of exactly this rank's rows; ``recv``: the root's
+    (world, block_rows, width) receive buffer, kept across passes likewise."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_bounds(n_total, world, rank)
     if block is None:
-        block = torch.empty((hi - lo, width), dtype=dtype, device=device)
-    assert block.shape == (hi - lo, width)
+        block = torch.zeros((block_rows(n_total, world), width), dtype=dtype, device=device)
+    assert block.shape[1] == width and block.shape[0] in (hi - lo, block_rows(n_total, world)), block.shape
     for m0, m1 in micro_batches(lo, hi, micro_batch):
         process(m0, m1, block[m0 - lo:m1 - lo])
     counts = [shard_bounds(n_total, world, q)[1] - shard_bounds(n_total, world, q)[0] for q in range(world)]
-    return gather_to_root(block, counts, async_op=async_op)
+    return gather_to_root(block, counts, async_op=async_op, recv=recv)
 
 
 def unpack_outputs(packed, s):
@@ -111,24 +120,40 @@ class PendingGather:
         return self._out if self._counts is None else _trim(self._out, self._counts)
 
 
-def gather_to_root(packed: torch.Tensor, counts: list[int] | None = None, dst: int = 0, async_op: bool = False):
+def gather_to_root(packed: torch.Tensor, counts: list[int] | None = None, dst: int = 0, async_op: bool = False, recv=None):
     """One gather of every rank's packed block to ``dst``.  Returns the concatenated (N_total, F)
     tensor on ``dst`` and None elsewhere (``async_op``: a ``PendingGather`` whose ``wait()`` returns that).
-    ``counts`` (rows per rank) allows ragged shards: blocks are padded to the largest and trimmed on the root."""
+    ``counts`` (rows per rank) allows ragged shards: every rank sends max(counts) rows and the root trims.  A ``packed``
+    that already has max(counts) rows (its own rows first; ``sharded_pass`` keeps such a buffer) is sent as it stands; a
+    shorter one is copied into a padded buffer first.  ``recv``: a (world, max(counts), F) receive buffer to reuse on
+    ``dst`` (allocated per call otherwise)."""
+    own = packed.shape[0] if counts is None else None
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collectives()):
+        if counts is not None and packed.shape[0] > counts[0]:
+            packed = packed[:counts[0]]
         return PendingGather(None, packed, None, True, None) if async_op else packed
     world, rank = dist.get_world_size(), dist.get_rank()
-    counts = counts or [packed.shape[0]] * world
+    counts = counts or [own] * world
     rows = max(counts)
     if packed.shape[0] < rows:
-        pad = torch.zeros((rows - packed.shape[0], packed.shape[1]), dtype=packed.dtype, device=packed.device)
-        packed = torch.cat([packed, pad], 0)
+        padded = torch.zeros((rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        padded[:packed.shape[0]] = packed
+        packed = padded
+    assert packed.shape[0] == rows, (packed.shape, rows)
+    shape = (world, rows, packed.shape[1])
+
+    def _recv():
+        if recv is not None:
+            assert tuple(recv.shape) == shape and recv.dtype == packed.dtype and recv.device == packed.device, (recv.shape, shape)
+            return recv
+        return torch.empty(shape, dtype=packed.dtype, device=packed.device)
+
     global _GATHER_UNSUPPORTED
     work, out = None, None
     if not _GATHER_UNSUPPORTED:
         try:
             if rank == dst:
-                out = torch.empty((world, rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+                out = _recv()
                 work = dist.gather(packed, list(out.unbind(0)), dst=dst, async_op=True)
             else:
                 work = dist.gather(packed, None, dst=dst, async_op=True)
@@ -138,7 +163,7 @@ def gather_to_root(packed: torch.Tensor, counts: list[int] | None = None, dst: i
             if rank == dst:
                 print(f"[shard] dist.gather unavailable ({type(e).__name__}); using all_gather_into_tensor", flush=True)
     if work is None:
-        out = torch.empty((world, rows, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        out = _recv() if rank == dst else torch.empty(shape, dtype=packed.dtype, device=packed.device)
         work = dist.all_gather_into_tensor(out, packed, async_op=True)
     pending = PendingGather(work, out, counts, rank == dst, packed)
     return pending if async_op else pending.wait()

@@ -69,3 +69,38 @@ def test_bench_step_through_rccl_one_rank(extra):
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert "RCCL gather" in line["config"]["parallelism"]
     assert line["scaling"] == ("strong" if extra else "weak")
+
+
+def test_two_ranks_on_one_card_gather_the_one_rank_block(tmp_path):
+    """bench.py --total 96 --batch 16 with TWO ranks sharing the card (gloo + HOLO_SHARE_GPU=1: RCCL refuses two ranks on one
+    device): the block gathered on rank 0 equals the block of a one-rank run bit for bit — the shards, the micro-batches, the
+    padded send buffers and the root's receive buffer put every hologram's outputs where the unsharded pass puts them — and the
+    line carries the gather's own time.  A ragged total (95) goes through the padded path."""
+    import torch
+    blocks = {}
+    for total in (96, 95):
+        for world in (1, 2):
+            path = str(tmp_path / f"block_{total}_{world}.pt")
+            args = ["bench.py", "--gpus", str(world), "--total", str(total), "--batch", "16", "--size", "64", "--steps", "2", "--warmup", "1",
+                    "--cpu-sample", "0", "--no-events", "--dump-block", path]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=REPO)
+            for k in ("HOLO_FORCE_DIST", "RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            if world == 1:
+                cmd = [sys.executable] + args
+            else:
+                env.update(HOLO_DIST_BACKEND="gloo", HOLO_SHARE_GPU="1")
+                cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                       "--master-port", str(29620 + (total % 2))] + args
+            r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+            line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            assert line["n_gpus"] == world and line["scaling"] == "strong" and line["config"]["total_holograms"] == total
+            if world == 2:
+                assert line["gather_ms"] > 0 and "gloo gather" in line["config"]["parallelism"]
+                assert line["roofline"]["traffic"] is None if "roofline" in line else True
+            blocks[(total, world)] = torch.load(path)
+        one, two = blocks[(total, 1)], blocks[(total, 2)]
+        assert one.shape == two.shape == (total, 4 * 64 * 64 + 1)
+        assert torch.equal(one, two), total
+        assert not torch.equal(one[0], one[total - 1])

@@ -102,7 +102,7 @@ def test_micro_batches_have_no_short_tail():
                 assert {Plan.batch_bucket(v) for v in sizes} == {16}
 
 
-def _strong_worker(rank, world, port, n_total, size, micro, out_path):
+def _strong_worker(rank, world, port, n_total, size, micro, out_path, padded):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from style_transfer_based_holographic_imaging_amd import shard
@@ -118,10 +118,21 @@ def _strong_worker(rank, world, port, n_total, size, micro, out_path):
         seen.append((m0, m1))
 
     lo, hi = shard.shard_bounds(n_total, world, rank)
-    block = torch.empty((hi - lo, width))
-    for _ in range(2):              # two passes reusing the block buffer, like bench.py --total
-        pend = shard.sharded_pass(n_total, micro, process, width, torch.device("cpu"), async_op=True, block=block)
+    recv = None
+    if padded:                      # bench.py --total: send buffer of the padded block size + the root's receive buffer, kept for the job
+        rows = shard.block_rows(n_total, world)
+        block = torch.zeros((rows, width))
+        recv = torch.full((world, rows, width), -7.0) if rank == 0 else None
+        ptrs = (block.data_ptr(), recv.data_ptr() if recv is not None else 0)
+    else:
+        block = torch.empty((hi - lo, width))
+    for _ in range(2):              # two passes reusing the buffers, like bench.py --total
+        pend = shard.sharded_pass(n_total, micro, process, width, torch.device("cpu"), async_op=True, block=block, recv=recv)
         gathered = pend.wait()
+    if padded:
+        assert ptrs == (block.data_ptr(), recv.data_ptr() if recv is not None else 0)
+        if rank == 0 and world * rows == n_total:       # an even job comes back as a VIEW of the receive buffer: nothing was copied
+            assert gathered.data_ptr() == recv.data_ptr()
     assert seen[:len(seen) // 2] == seen[len(seen) // 2:] == shard.micro_batches(lo, hi, micro)
     if rank == 0:
         torch.save(gathered, out_path)
@@ -131,13 +142,14 @@ def _strong_worker(rank, world, port, n_total, size, micro, out_path):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("padded", [False, True])
 @pytest.mark.parametrize("n_total,micro", [(11, 4), (8, 3), (1, 4)])     # ragged blocks, ragged micro-batches, an empty rank
-def test_two_rank_strong_scaling_pass(tmp_path, n_total, micro):
+def test_two_rank_strong_scaling_pass(tmp_path, n_total, micro, padded):
     """bench.py --total: a fixed job sharded over 2 ranks, micro-batched, ONE gather of each rank's packed block."""
     from style_transfer_based_holographic_imaging_amd import shard
     world, size = 2, 4
     out_path = str(tmp_path / "gathered.pt")
-    mp.spawn(_strong_worker, args=(world, _free_port(), n_total, size, micro, out_path), nprocs=world, join=True)
+    mp.spawn(_strong_worker, args=(world, _free_port(), n_total, size, micro, out_path, padded), nprocs=world, join=True)
     g = torch.load(out_path)
     assert g.shape == (n_total, shard.packed_width(size))
     amp, ph, a_f, p_f, d = shard.unpack_outputs(g, size)

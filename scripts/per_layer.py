@@ -19,8 +19,10 @@ ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--conv-algo", default="auto")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--tile", type=int, default=0, help="holo_debug_set_conv_tile variant (A/B of the implicit-GEMM kernel's tiles)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+ops.set_conv_tile(a.tile)
 network, _ = bench.build_network(dev)
 network.set_conv_algo(a.conv_algo)
 if a.dtype != "f32":

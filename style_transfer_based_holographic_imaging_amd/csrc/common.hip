@@ -27,7 +27,7 @@ const char* holo_source_hash(void) { return kSourceHashTag + sizeof("@(#)holo_so
 // the toolchain the object was compiled with: read by the build recipe only (a reason to REbuild, never a reason to refuse a load)
 __attribute__((used)) static const char kRocmVersionTag[] = "@(#)holo_rocm_version=" HOLO_ROCM_VERSION;
 int holo_debug_set_conv_tile(int tile) {
-    HOLO_REQUIRE(tile >= 0 && tile <= 3, HOLO_ERR_ARG, "holo_debug_set_conv_tile: tile=%d outside [0,3]", tile);
+    HOLO_REQUIRE(tile >= 0 && tile <= 9, HOLO_ERR_ARG, "holo_debug_set_conv_tile: tile=%d outside [0,9]", tile);
     holo::g_conv_tile = tile;
     return HOLO_OK;
 }

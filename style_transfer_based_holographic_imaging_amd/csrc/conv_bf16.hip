@@ -1,0 +1,390 @@
+// bf16 3x3 convolutions on v_mfma_f32_16x16x32_bf16 (BASELINE configs[2]: "bf16 convs / fp32 FFT").
+//
+// Replaces  ReflectionPad2d(1) -> Conv2d(3x3) -> ReLU [-> MaxPool2d(2,2,ceil_mode=True)]  of net.py:78-107 / net.py:34-71 with
+// bf16 activations and weights and fp32 accumulation, like conv_mfma_kernel<bf16> (conv_mfma.hip), which it supersedes for the
+// layers it covers; same NHWC activations, same packed weights [Cin/32][tap][Cout][32], same results (every accumulator sums its
+// 9*Cin products in the same order: chunk-major, tap, then k; the 16x16x32 instruction adds 32 products per step where the
+// 32x32x16 one adds 16 — fp32 rounding of partial sums only).
+//
+// What is different, and why (profiles/r04_bf16_tile_sweep.txt):
+//   * 8-wave blocks of 512 pixels x 128 output channels: one staged weight tile (8 KB per 32-channel chunk and tap) now feeds 512
+//     pixels instead of 128.  The old tile moved 36 B/clk/CU from L2 into LDS at full matrix rate and ran at 45 %; this one 12.6.
+//   * v_mfma_f32_16x16x32_bf16: the chip holds a higher clock on it than on the 32x32x16 shape (MI355X_MICROARCH.md, DVFS give-back
+//     item 7).  A lane's 16-byte LDS read is a whole K = 32 fragment of one row, so a stage (tap) is 4 pixel + WTN weight reads.
+//   * the product is computed transposed (D[channel][pixel]): a lane ends up with 4 consecutive channels of ONE pixel per tile;
+//     v_permlane16_swap joins the quads of neighbouring 16-lane rows into 16-byte runs, so a store instruction writes 64-byte
+//     runs of the NHWC pixel.
+//
+// LDS images (64-byte rows = 32 channels, 16-byte units XOR-swizzled so that every ds_read_b128 lane group covers 16 different
+// 16-byte slots — found by enumeration, scratch/swz_search.py):
+//   halo tile   [HR x 18 pixels][64 B]   unit' = unit ^ (((hx >> 1) & 1) << 1)      (needs HW = 2 mod 4)
+//   weight tile [TN channels][64 B]      unit' = unit ^ g[(co >> 2) & 3], g = {0,2,3,1}
+// Both are filled by LDS-DMA (global_load_lds_dwordx4: lane-linear destination, swizzle applied to the per-lane SOURCE address).
+#include "common.h"
+
+#ifndef HOLO_B16_ABLATE
+#define HOLO_B16_ABLATE 0      // timing experiments only (wrong results): 1 = no staging loads in the main loop, 2 = no waits / barriers, 4 = no fragment reads, 8 = no stores
+#endif
+
+namespace holo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b16_t;
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kB16KC = 32;     // channels per stage
+constexpr int kB16HW = 18;     // halo width: 16 pixel columns + 2
+
+// WM x WN waves; a wave owns 64 pixels (4 rows x 16 columns = 2 x 2 tiles of 2 rows x 8 columns) x (16 * WTN) output channels.
+// A stage is one KERNEL ROW of a 32-channel chunk (3 taps): the weight tiles of its three taps are staged together, so a
+// block meets at a barrier once per 3 * 4 * WTN MFMAs per wave (1536 cycles at WTN = 8) instead of once per tap.
+template <int WM, int WN, int WTN>
+struct B16Cfg {
+    static constexpr int PR = 4 * WM;
+    static constexpr int TN = 16 * WTN * WN;
+    static constexpr int HR = PR + 2;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int A_UNITS = HR * kB16HW * 4;
+    static constexpr int A_ROUNDS = (A_UNITS + THREADS - 1) / THREADS;
+    // the LDS images are padded to whole block-wide rounds: EVERY wave issues A_ROUNDS (+ BS_ROUNDS) loads, so one counted
+    // s_waitcnt vmcnt(N) is right for all of them (lanes past the image load a valid dummy unit into the padding)
+    static constexpr int A_BYTES = A_ROUNDS * THREADS * 16;
+    static constexpr int BT_UNITS = TN * 4;                 // one tap's weight tile
+    static constexpr int BT_BYTES = BT_UNITS * 16;
+    static constexpr int BS_UNITS = 3 * BT_UNITS;           // one stage: three taps
+    static constexpr int BS_ROUNDS = (BS_UNITS + THREADS - 1) / THREADS;
+    static constexpr int BS_BYTES = BS_ROUNDS * THREADS * 16;
+    static constexpr int DMA_STEP = WTN >= 8 ? 2 : 1;       // MFMA groups between two staging loads of a wave
+    static constexpr int NBUF_B = 3;
+    static constexpr int LDS_BYTES = 2 * A_BYTES + NBUF_B * BS_BYTES;
+    static_assert(BT_UNITS % 64 == 0, "weight tiles are whole 1-KiB pieces");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+__device__ __forceinline__ int b16_swz_a(int hx) { return ((hx >> 1) & 1) << 1; }
+__device__ __forceinline__ int b16_swz_b(int co) { return (0x78 >> (((co >> 2) & 3) * 2)) & 3; }   // {0,2,3,1} packed two bits each: 0b01'11'10'00
+
+// One tile = 4*WM rows x 16 columns of one image x TN output channels.  Tile ids are decoded nb-fastest (the channel blocks of a
+// patch are neighbours and meet in one L2), then tx, ty, image.
+struct B16Tile {
+    int img, y0, x0, n0;
+};
+__device__ __forceinline__ B16Tile b16_decode(int t, int n_blk, int tiles_x, int tiles_y, int pr, int tn) {
+    B16Tile o;
+    const int nb = t % n_blk;
+    t /= n_blk;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    o.img = t / tiles_y;
+    o.y0 = ty * pr;
+    o.x0 = tx * 16;
+    o.n0 = nb * tn;
+    return o;
+}
+
+// PERSISTENT blocks (one per CU: the LDS images take 150 KB): a block walks tiles L, L + grid, ... and its staging runs as ONE
+// stream across tile boundaries — the first halo tile and the first two weight stages of the next tile are requested during the
+// last stages of the current one, exactly as inside a tile.  (As one block per tile the kernel paid ~19 k cycles per block —
+// launch, plan, the first loads' latency, drain — on 74 k cycles of matrix work: profiles/r04_bf16_conv_pmc.json.)
+template <int WM, int WN, int WTN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv3x3_b16_kernel(
+    const b16_t* __restrict__ x, const b16_t* __restrict__ wp, const float* __restrict__ bias, b16_t* __restrict__ y,
+    int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int total_tiles, int relu, int pool) {
+    using C = B16Cfg<WM, WN, WTN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_a = smem;                   // [2][A_BYTES]
+    unsigned char* lds_b = smem + 2 * C::A_BYTES;  // [3][BS_BYTES]
+
+    const int tid = threadIdx.x;
+    const int n_blk = Cout / C::TN;
+    // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): the blocks of one XCD take a contiguous range of tile ids
+    // in every round, so the channel blocks of a patch and neighbouring patches meet in one L2.  Speed only.
+    int first = blockIdx.x;
+    if ((gridDim.x & 7) == 0) first = (first & 7) * (gridDim.x >> 3) + (first >> 3);
+    const int nchunks = Cin / kB16KC;
+    const int nstages = 3 * nchunks;
+    const size_t img_elems = (size_t)H * W * Cin;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically): the upper half issues its staging
+    // loads one MFMA group later than the lower half, so that a SIMD's two waves are never both busy issuing them
+    const int wave_hi = __builtin_amdgcn_readfirstlane(wave >= (WM * WN) / 2 ? 1 : 0);
+    // halo staging plan of a tile: unit u = tid + r * THREADS of the LDS image <- 16-byte unit ((u & 3) ^ swizzle) of halo pixel u >> 2
+    // (reflection resolved here); byte offsets within the image (< 2^32: entry check)
+    int a_q[C::A_ROUNDS];      // per round: hy * 32 + hx and the source unit, packed (tile independent)
+#pragma unroll
+    for (int r = 0; r < C::A_ROUNDS; ++r) {
+        const int u = tid + r * C::THREADS;
+        const int q = u < C::A_UNITS ? u >> 2 : 0;            // padding lanes: a valid dummy source
+        const int hy = q / kB16HW, hx = q % kB16HW;
+        a_q[r] = (hy << 16) | (hx << 8) | ((u & 3) ^ b16_swz_a(hx));
+    }
+#define B16_PLAN(dst_, tile_)                                                                              \
+    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                              \
+        const int ry = reflect1((tile_).y0 - 1 + (a_q[r] >> 16), H);                                       \
+        const int rx = reflect1((tile_).x0 - 1 + ((a_q[r] >> 8) & 255), W);                                \
+        dst_[r] = (unsigned)((ry * W + rx) * Cin + 8 * (a_q[r] & 255)) * 2u;                               \
+    }
+    // weight tiles of one stage: unit u = tap t, output channel co, 16-byte unit; the taps' tiles are Cout * 64 bytes apart in the
+    // packed weights [chunk][tap][Cout][32] and contiguous in LDS
+    int b_src[C::BS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < C::BS_ROUNDS; ++r) {
+        const int u = tid + r * C::THREADS < C::BS_UNITS ? tid + r * C::THREADS : 0;     // padding lanes: a valid dummy source
+        const int t = u / C::BT_UNITS, v = u % C::BT_UNITS;
+        const int co = v >> 2, c = (v & 3) ^ b16_swz_b(co);
+        b_src[r] = t * Cout * (kB16KC * 2) + (co * kB16KC + 8 * c) * 2;
+    }
+    const int wave_base = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+    const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
+// LDS-DMA from inline asm (through the builtin hipcc drains vmcnt(0) before the next ds_read: conv_mfma.hip); wave-uniform
+// 64-bit base in SGPRs + 32-bit per-lane byte offset; M0 (the LDS base of the DMA) is saved and restored
+#define B16_GLDS(sbase_, voff_, ldst_)                                                                      \
+    {                                                                                                      \
+        unsigned m0_keep;                                                                                  \
+        const unsigned lds_u = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(ldst_));               \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t" \
+                     "s_mov_b32 m0, %0"                                                                     \
+                     : "=&s"(m0_keep)                                                                      \
+                     : "v"(voff_), "s"(sbase_), "s"(lds_u)                                                 \
+                     : "memory");                                                                          \
+    }
+#define B16_LOAD_A1(r_, src_, xchunk_, buf_) B16_GLDS((xchunk_), src_[r_], (buf_) * C::A_BYTES + (r_) * C::THREADS * 16 + wave_base)
+#define B16_LOAD_B1(r_, wsrc_, buf_) B16_GLDS((wsrc_), b_src[r_], 2 * C::A_BYTES + (buf_) * C::BS_BYTES + (r_) * C::THREADS * 16 + wave_base)
+#define B16_LOAD_A(src_, xchunk_, buf_) _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) { B16_LOAD_A1(r, src_, xchunk_, buf_) }
+#define B16_LOAD_B(wsrc_, buf_) _Pragma("unroll") for (int r = 0; r < C::BS_ROUNDS; ++r) { B16_LOAD_B1(r, wsrc_, buf_) }
+#define B16_WAIT_N(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+
+    // ---- per-lane operand coordinates -----------------------------------------------------------------------
+    // tile pixel p = lane & 15 -> (x, y) = ((p & 1) | ((p >> 2) << 1), (p >> 1) & 1): 2 rows x 8 columns, and a 2 x 2 pooling
+    // window is the 4 lanes 4g .. 4g+3.  k-unit u = lane >> 4.  Pixel tile mt: columns (mt & 1) * 8, rows (mt >> 1) * 2.
+    const int p = lane & 15, ku = lane >> 4;
+    const int lpx = (p & 1) | ((p >> 2) << 1);
+    const int lpy = wm * 4 + ((p >> 1) & 1);
+    const int b_off0 = (wn * (16 * WTN) + p) * 64 + ((ku ^ b16_swz_b(p)) << 4);    // + nt * 1024 (16 rows further: same swizzle)
+    // halo reads: pixel (lpx + 8*(mt&1) + dx, lpy + 2*(mt>>1) + dy); the swizzle bit follows bit 1 of the column, which the
+    // tile offset 8 leaves alone: three per-lane bases (one per dx), everything else is an immediate offset
+    int a_lane[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) a_lane[dx] = (lpy * kB16HW + lpx) * 64 + ((ku ^ b16_swz_a(lpx + dx)) << 4);
+
+    if (first >= total_tiles) return;
+    const size_t w_stage = (size_t)3 * Cout * kB16KC;
+    B16Tile cur = b16_decode(first, n_blk, tiles_x, tiles_y, C::PR, C::TN);
+    unsigned a_src[C::A_ROUNDS];
+    B16_PLAN(a_src, cur)
+    {
+        const b16_t* w0 = wp + (size_t)cur.n0 * kB16KC;
+        B16_LOAD_A(a_src, x + cur.img * img_elems, 0)
+        B16_LOAD_B(w0, 0)
+        B16_LOAD_B(w0 + w_stage, 1)           // Cin >= 32: at least three stages exist
+    }
+    B16_WAIT_N(0);
+    __syncthreads();
+
+    int apar = 0;
+    for (int t = first; t < total_tiles; t += gridDim.x) {
+        const bool more_tiles = t + (int)gridDim.x < total_tiles;
+        const B16Tile nxt = b16_decode(more_tiles ? t + (int)gridDim.x : t, n_blk, tiles_x, tiles_y, C::PR, C::TN);
+        const b16_t* __restrict__ ximg = x + cur.img * img_elems;
+        const b16_t* __restrict__ xnxt = x + nxt.img * img_elems;
+        const b16_t* __restrict__ wcur = wp + (size_t)cur.n0 * kB16KC;
+        const b16_t* __restrict__ wnxt = wp + (size_t)nxt.n0 * kB16KC;
+
+        f32x4 acc[4][WTN];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WTN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- stages: chunk-major, three stages (kernel rows) per chunk, fully unrolled inside a stage.  Weight tiles are triple
+        // buffered: stage s issues the loads of stage s + 2 (of the next tile past the end) at its start and waits for them at
+        // its end (they have the whole stage to land), so after the barrier that ends stage s the data of stages s + 1 and s + 2
+        // are visible.  The halo tile of the next chunk (of the next tile's first chunk) is requested at the start of a chunk's
+        // second stage.  Inside a stage the fragment reads run two MFMA groups ahead of their use (weight fragments in a ring of
+        // three, the next tap's pixel fragments in the other half of a double buffer).
+        int stage = 0;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const bool more_chunks = chunk + 1 < nchunks;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy, ++stage) {
+                const unsigned char* abuf = lds_a + apar * C::A_BYTES;
+                const unsigned char* bbuf = lds_b + dy * C::BS_BYTES;          // stage % 3 == dy
+                b16x8 afr[2][4], bfr[3];
+#if HOLO_B16_ABLATE & 4      // timing only: no fragment reads (every MFMA takes the same two registers)
+#define B16_READ_A(t_, mt_) frag_const
+#define B16_READ_B(t_, nt_) frag_const
+                b16x8 frag_const = *reinterpret_cast<const b16x8*>(abuf + a_lane[0]);
+                asm volatile("" : "+v"(frag_const));
+#else
+#define B16_READ_A(t_, mt_) *reinterpret_cast<const b16x8*>(abuf + a_lane[t_] + ((((mt_) >> 1) * 2 + dy) * kB16HW + ((mt_) & 1) * 8 + (t_)) * 64)
+#define B16_READ_B(t_, nt_) *reinterpret_cast<const b16x8*>(bbuf + (t_) * C::BT_BYTES + b_off0 + (nt_) * 1024)
+#endif
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) afr[0][mt] = B16_READ_A(0, mt);
+                bfr[0] = B16_READ_B(0, 0);
+                bfr[1] = B16_READ_B(0, 1);
+                // this stage's staging loads: the weight tiles of stage + 2 (of the next tile past the end), then — in a chunk's
+                // FIRST stage — the halo tile of the next chunk (of the next tile's first chunk).  They are issued one at a time
+                // between the MFMA groups below.  The weight loads are waited for at the end of this stage; the halo loads, which
+                // come from HBM, stay in flight for another stage (counted wait: they are younger than the weight loads).
+                const b16_t* wdma = stage + 2 < nstages ? wcur + (size_t)(stage + 2) * w_stage
+                                                        : wnxt + (size_t)(stage + 2 - nstages) * w_stage;
+                const bool dma_b = !(HOLO_B16_ABLATE & 1) && (stage + 2 < nstages || more_tiles);
+                const bool dma_a = !(HOLO_B16_ABLATE & 1) && dy == 0 && (more_chunks || more_tiles);
+                const b16_t* xdma = more_chunks ? ximg + (chunk + 1) * kB16KC : xnxt;
+                unsigned a_use[C::A_ROUNDS];
+                if (dy == 0) {
+                    if (more_chunks) {
+#pragma unroll
+                        for (int r = 0; r < C::A_ROUNDS; ++r) a_use[r] = a_src[r];
+                    } else {   // the next tile's plan, made where it is needed (not kept across the tile: registers)
+                        B16_PLAN(a_use, nxt)
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 3 * WTN; ++g) {
+                    const int tt = g / WTN, nt = g % WTN;
+                    // staging load k goes behind group 1 + k * DMA_STEP (+ 1 in the upper waves)
+#pragma unroll
+                    for (int k = 0; k < C::BS_ROUNDS + (dy == 0 ? C::A_ROUNDS : 0); ++k) {
+                        if (g == 1 + k * C::DMA_STEP || g == 2 + k * C::DMA_STEP) {
+                            if (wave_hi == (g - 1 - k * C::DMA_STEP)) {
+                                if (k < C::BS_ROUNDS) {
+                                    if (dma_b) { B16_LOAD_B1(k, wdma, (dy + 2) % 3) }
+                                } else {
+                                    if (dma_a) { B16_LOAD_A1(k - C::BS_ROUNDS, a_use, xdma, apar ^ 1) }
+                                }
+                            }
+                        }
+                    }
+                    if (g + 2 < 3 * WTN) bfr[(g + 2) % 3] = B16_READ_B((g + 2) / WTN, (g + 2) % WTN);
+                    if (tt < 2) {
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            if (nt == (mt * WTN) / 4) afr[(tt + 1) & 1][mt] = B16_READ_A(tt + 1, mt);
+                    }
+                    // D[m = channel][n = pixel] += W[channel][k] * X[pixel][k]
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[g % 3], afr[tt & 1][mt], acc[mt][nt], 0, 0, 0);
+                }
+#undef B16_READ_A
+#undef B16_READ_B
+#if !(HOLO_B16_ABLATE & 2)
+                if (stage + 1 < nstages || more_tiles) {
+                    // this wave's weight loads of the stage have landed; a chunk's first stage leaves its halo loads in flight
+                    if (dy == 0 && dma_a) { B16_WAIT_N(C::A_ROUNDS); }
+                    else { B16_WAIT_N(0); }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this stage's fragment reads are done
+                    __builtin_amdgcn_s_barrier();         // raw barrier
+                    asm volatile("" ::: "memory");
+                }
+#endif
+            }
+            apar ^= 1;
+        }
+
+        // ---- epilogue: bias, ReLU, optional 2x2 max-pool, bf16, 16-byte NHWC stores -------------------------------------------
+        // tile (mt, nt): lane (p, h = lane >> 4) holds channels nt*16 + 4h .. 4h+3 of its pixel = 8 bytes of bf16.  For a pair of
+        // channel tiles (nt, nt+1), v_permlane16_swap (lanes 16-31 of the first operand <-> lanes 0-15 of the second, same for the
+        // upper half) leaves rows h = 0 / 2 with channels 0-7 / 8-15 of tile nt+1 and rows 1 / 3 with those of tile nt.
+        const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+        const int cwave = cur.n0 + wn * (16 * WTN);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int X = cur.x0 + lpx + (mt & 1) * 8, Y = cur.y0 + lpy + (mt >> 1) * 2;
+            const bool inside = X < W && Y < H;
+            bool writer = inside;
+            size_t pix;
+            b16_t* __restrict__ yimg;
+            if (!pool) {
+                yimg = y + (size_t)cur.img * H * W * Cout;
+                pix = (size_t)Y * W + X;
+            } else {
+                yimg = y + (size_t)cur.img * Ho * Wo * Cout;
+                writer = inside && (p & 3) == 0;          // the window's top-left pixel stores
+                pix = (size_t)(Y >> 1) * Wo + (X >> 1);
+            }
+#pragma unroll
+            for (int nt = 0; nt < WTN; nt += 2) {
+                unsigned pk[2][2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + cwave + (nt + h2) * 16 + 4 * ku);
+                    const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float s = acc[mt][nt + h2][i] + bq[i];
+                        s = relu ? fmaxf(s, 0.0f) : s;
+                        if (pool) {
+                            // MaxPool2d(2,2,ceil_mode=True): window = lanes 4g..4g+3; members beyond the image edge count as 0
+                            // (pooling follows a ReLU)
+                            s = inside ? s : 0.0f;
+                            s = fmaxf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true)));
+                            s = fmaxf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true)));
+                        }
+                        v[i] = s;
+                    }
+                    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+                    const b16x2 lo = {(b16_t)v[0], (b16_t)v[1]}, hi = {(b16_t)v[2], (b16_t)v[3]};
+                    pk[h2][0] = __builtin_bit_cast(unsigned, lo);
+                    pk[h2][1] = __builtin_bit_cast(unsigned, hi);
+                }
+                // first operand = tile nt+1's quad, second = tile nt's
+                const auto s0 = __builtin_amdgcn_permlane16_swap(pk[1][0], pk[0][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(pk[1][1], pk[0][1], false, false);
+                const uint4 run = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                const int ch = cwave + nt * 16 + ((ku & 1) ? 0 : 16) + (ku >> 1) * 8;
+                if (writer && (!(HOLO_B16_ABLATE & 8) || run.x == 0x12345678u)) *reinterpret_cast<uint4*>(yimg + pix * Cout + ch) = run;
+            }
+        }
+        cur = nxt;
+        B16_PLAN(a_src, cur)
+    }
+}
+
+#undef B16_GLDS
+#undef B16_LOAD_A
+#undef B16_LOAD_B
+#undef B16_LOAD_A1
+#undef B16_LOAD_B1
+#undef B16_WAIT_N
+#undef B16_PLAN
+
+template <int WM, int WN, int WTN>
+static int launch_conv_b16(const b16_t* x, const b16_t* wp, const float* bias, b16_t* y, int batch, int h, int w, int cin, int cout,
+                           int relu, int pool, hipStream_t stream) {
+    using C = B16Cfg<WM, WN, WTN>;
+    const int tiles_x = ceil_div(w, 16), tiles_y = ceil_div(h, C::PR);
+    const long tiles = (long)batch * tiles_x * tiles_y * (cout / C::TN);
+    HOLO_REQUIRE(tiles > 0 && tiles < 2147483647L, HOLO_ERR_UNSUPPORTED, "conv: %ld tiles", tiles);
+    static DeviceOnce attr_once;
+    attr_once.run([] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_b16_kernel<WM, WN, WTN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    });
+    const long cus = device_cus();      // one block per CU (LDS); every block reaches the end of its tile list: no block waits for another
+    const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
+    hipLaunchKernelGGL((conv3x3_b16_kernel<WM, WN, WTN>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, x, wp, bias, y,
+                       h, w, cin, cout, tiles_x, tiles_y, (int)tiles, relu, pool);
+    return check_launch("holo_conv3x3_bf16");
+}
+
+// Called by conv3x3_entry<bf16> (conv_mfma.hip) for the layers this kernel covers; returns -1 when it does not take the layer.
+int conv3x3_b16_try(const void* x, const void* wp, const float* bias, void* y, int batch, int h, int w, int cin, int cout, int relu,
+                    int pool, int variant, hipStream_t stream) {
+    const b16_t* xb = static_cast<const b16_t*>(x);
+    const b16_t* wb = static_cast<const b16_t*>(wp);
+    b16_t* yb = static_cast<b16_t*>(y);
+    (void)variant;
+    if (cin % 32 != 0) return -1;
+    if (cout % 128 == 0) return launch_conv_b16<8, 1, 8>(xb, wb, bias, yb, batch, h, w, cin, cout, relu, pool, stream);   // 512 px x 128 co
+    if (cout % 64 == 0) return launch_conv_b16<8, 1, 4>(xb, wb, bias, yb, batch, h, w, cin, cout, relu, pool, stream);    // 512 px x 64 co
+    return -1;
+}
+
+}  // namespace holo

@@ -112,7 +112,11 @@ struct ConvCfg {
     // issues the same number of weight loads): stage s issues the loads of stage s+2 and the wait at its end leaves exactly those
     // in flight (counted vmcnt; loads complete in order), followed by a RAW s_barrier behind an lgkmcnt-only wait —
     // __syncthreads() would drain the LDS-DMA queue (its fence waits for vmcnt(0)).  +8 % bf16, +5 % f32s, +0.6 % fp32.
-    static constexpr int NBUF_B = (!CONVT && !HOLO_CONV_PRIVATE_B && HOLO_CONV_TRIPLE_B && TAPS % 3 == 0 && B_UNITS % THREADS == 0 && (HOLO_CONV_TRIPLE_F32 || !__is_same(T, float))) ? 3 : 2;
+    // A weight tile smaller than one block-wide round (64 output channels under an 8-wave block) is loaded by the first
+    // B_TAIL_WAVES waves only; the counted waits then use the wave's own number of weight loads per stage.
+    static constexpr int B_TAIL_WAVES = (B_UNITS % THREADS) / 64;
+    static_assert(B_UNITS % 64 == 0, "weight tiles are whole 1-KiB pieces");
+    static constexpr int NBUF_B = (!CONVT && !HOLO_CONV_PRIVATE_B && HOLO_CONV_TRIPLE_B && TAPS % 3 == 0 && (HOLO_CONV_TRIPLE_F32 || !__is_same(T, float))) ? 3 : 2;
     static constexpr int A_MIN_ROUNDS = A_UNITS % THREADS == 0 ? A_ROUNDS : A_ROUNDS - 1;
     static constexpr int LDS_BYTES = 2 * A_BYTES + (HOLO_CONV_PRIVATE_B ? WM * WN * 2 * BW_BYTES : NBUF_B * B_BYTES);
     // A is re-staged every chunk; for CONVT every stage is a new chunk
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
         a_src[r] = (unsigned)((ry * W + rx) * Cin + C::EPU * c) * (unsigned)C::ES;   // byte offset within the image (< 2^32: entry check)
     }
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform copy for scalar branches
     const int wm = wave / WN, wn = wave % WN;
 #if HOLO_CONV_PRIVATE_B
     // Experiment (off by default): weight tile WAVE-PRIVATE — unit u = lane + 64*r of this wave's region holds
@@ -264,6 +269,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
 #endif
 #define HOLO_STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define HOLO_STAGE_WAIT_N(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+// leave this wave's weight loads of ONE stage (+ extra_ halo loads) in flight: a wave beyond the tail of a partial round has one fewer
+#define HOLO_STAGE_WAIT_B(extra_)                                                                          \
+    {                                                                                                     \
+        if (C::B_TAIL_WAVES == 0 || wave_s < C::B_TAIL_WAVES) { HOLO_STAGE_WAIT_N(C::B_ROUNDS + (extra_)); } \
+        else { HOLO_STAGE_WAIT_N(C::B_ROUNDS - 1 + (extra_)); }                                           \
+    }
 
     // ---- per-lane MFMA operand coordinates -----------------------------------------------------------
     const int hsel = lane >> 5, li = lane & 31;
@@ -451,10 +462,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
 #if !(HOLO_CONV_ABLATE & 2)
             if constexpr (NB == 3) {
                 if (has_next) {
-                    if (tap + 2 <= kLast) { HOLO_STAGE_WAIT_N(C::B_ROUNDS); }
+                    if (tap + 2 <= kLast) { HOLO_STAGE_WAIT_B(0) }
                     else if (!more_chunks) { HOLO_STAGE_WAIT(); }
-                    else if (tap == kLast - 1) { HOLO_STAGE_WAIT_N(C::B_ROUNDS + C::A_MIN_ROUNDS); }
-                    else { HOLO_STAGE_WAIT_N(C::B_ROUNDS); }
+                    else if (tap == kLast - 1) { HOLO_STAGE_WAIT_B(C::A_MIN_ROUNDS) }
+                    else { HOLO_STAGE_WAIT_B(0) }
                     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0) only: the fragment reads of this stage are done
                     __builtin_amdgcn_s_barrier();          // a raw barrier: __syncthreads() would drain the in-flight DMAs
                     asm volatile("" ::: "memory");         // and no LDS access may be moved across it by the compiler
@@ -663,6 +674,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
 #undef HOLO_GLDS16_S
 #undef HOLO_STAGE_WAIT
 #undef HOLO_STAGE_WAIT_N
+#undef HOLO_STAGE_WAIT_B
 
 template <int WM, int WN, bool CONVT, int KC, typename T, int WTM = 2, int WTN = WTM>
 static int launch_conv(const T* x, const T* wp, const float* bias, T* y, int batch, int h, int w, int cin,
@@ -773,6 +785,10 @@ static int packt2x2_entry(const float* w_iohw, T* w_packed, int cin, int cout, v
     return check_launch("holo_pack_convt2x2_weight");
 }
 
+// conv_bf16.hip: the 8-wave v_mfma_f32_16x16x32_bf16 kernel; -1 when it does not take the layer
+int conv3x3_b16_try(const void* x, const void* wp, const float* bias, void* y, int batch, int h, int w, int cin, int cout, int relu,
+                    int pool, int variant, hipStream_t stream);
+
 template <typename T>
 static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, T* y_nhwc, int batch, int h, int w,
                          int cin, int cout, int relu, int pool, void* stream) {
@@ -797,6 +813,22 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
             return launch_conv<2, 2, false, KCD, T, 1>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
     }
     if constexpr (sizeof(T) == 2) {
+        // Large layers with Cout % 128 == 0: the 512 px x 128 co blocks of conv_bf16.hip, from 1.5 blocks per CU up
+        // (holo_debug_set_conv_tile 8 forces them, also for Cout = 64; 1 keeps the older kernel)
+        if (conv_kc<T>(cin, cout, false) == KCD &&
+            (force == 8 || (force == 0 && cout % 128 == 0 && (long)batch * ceil_div(w, 16) * ceil_div(h, 32) * (cout / 128) >= 384))) {
+            const int r = conv3x3_b16_try(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, 1, s);
+            if (r >= 0) return r;
+        }
+        // 8-wave blocks (holo_debug_set_conv_tile 4..7): more pixels (and output channels) per staged weight tile
+        if (force >= 4 && force <= 7 && conv_kc<T>(cin, cout, false) == KCD) {
+            if (cout % 128 != 0) return launch_conv<8, 1, false, KCD, T, 2, 2>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);   // 512 px x 64 co
+            if (force == 4) return launch_conv<4, 2, false, KCD, T, 2, 2>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);     // 256 px x 128 co
+            if (force == 5 || (force == 6 && cout % 256 != 0))
+                return launch_conv<8, 1, false, KCD, T, 2, 4>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);                 // 512 px x 128 co
+            if (force == 6) return launch_conv<4, 2, false, KCD, T, 2, 4>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);     // 256 px x 256 co
+            return launch_conv<4, 1, false, KCD, T, 2, 4>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);                     // 4 waves: 256 px x 128 co
+        }
         // Experiment, off unless holo_debug_set_conv_tile(3): wave tile 128 px x 64 co (4x2 MFMA tiles; 256 px x 128 co blocks,
         // or 512 px x 64 co for the 64-wide layers).  It halves the staged and re-read LDS bytes per MFMA, yet measured
         // SLOWER on MI355X (batch 64, 256x256: 746 TFLOP/s with 64-channel stages / one block per CU, 833 with

@@ -81,6 +81,45 @@ def test_conv3x3_bf16_tall_wave_tile(ops, dev, b, h, w, cin, cout, relu, pool):
     assert torch.equal(y, y_std)
 
 
+@pytest.mark.parametrize("tile", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("b,h,w,cin,cout,relu,pool", [
+    (2, 32, 32, 64, 128, True, False), (1, 21, 37, 128, 128, True, True), (1, 40, 16, 256, 256, False, False),
+    (2, 64, 48, 64, 64, True, True), (1, 35, 19, 128, 64, True, False), (1, 2, 2, 32, 64, True, False),
+    (1, 33, 17, 64, 512, True, True),
+])
+def test_conv3x3_bf16_eight_wave_tiles(ops, dev, tile, b, h, w, cin, cout, relu, pool):
+    """The 8-wave block tiles of the bf16 kernel (256 / 512 pixels x 64 / 128 / 256 output channels per staged weight tile;
+    the 64-channel weight tile is loaded by half the waves: counted waits per wave), forced on small shapes with partial
+    tiles: bit-identical to the standard tile (same K order per accumulator) and within bf16 rounding of the reference."""
+    g = torch.Generator().manual_seed(h * 100 + cin + 11)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(F.pad(_r(x), (1, 1, 1, 1), mode="reflect"), _r(wt), bias)
+    if relu:
+        ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
+    xp = ops.cast(ops.to_nhwc(x.to(dev)), BF)
+    wp = ops.pack_conv3x3(wt.to(dev), BF)
+    try:
+        ops.set_conv_tile(tile)
+        y = ops.conv3x3(xp, wp, bias.to(dev), cout, relu, pool)
+        y2 = ops.conv3x3(xp, wp, bias.to(dev), cout, relu, pool)
+        ops.set_conv_tile(1)
+        y_std = ops.conv3x3(xp, wp, bias.to(dev), cout, relu, pool)
+    finally:
+        ops.set_conv_tile(0)
+    got = ops.as_nchw_view(y).float().cpu()
+    assert got.shape == ref.shape and rel_err(got, ref) < 6e-3
+    assert torch.equal(y, y2)
+    if tile < 8:
+        assert torch.equal(y, y_std)
+    else:   # tile 8: the 16x16x32 kernel (conv_bf16.hip) adds 32 products per MFMA step instead of 16: fp32 rounding of partial sums, then bf16
+        assert rel_err(y.float().cpu(), y_std.float().cpu()) < 8e-3
+        assert float((y.float() - y_std.float()).abs().mean() / y_std.float().abs().mean()) < 2e-4
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout", [(2, 4, 4, 64, 64), (1, 7, 5, 128, 128), (1, 16, 16, 256, 256)])
 def test_convt2x2_bf16(ops, dev, b, h, w, cin, cout):
     g = torch.Generator().manual_seed(cin + h)

@@ -203,7 +203,7 @@ def test_library_carries_the_hash_of_its_sources_and_a_stale_one_is_refused(monk
 
 def test_debug_tile_hook_validates_its_argument():
     from style_transfer_based_holographic_imaging_amd._lib import lib
-    assert lib.holo_debug_set_conv_tile(7) == 1 and b"outside [0,3]" in lib.holo_last_error()
+    assert lib.holo_debug_set_conv_tile(17) == 1 and b"outside [0,9]" in lib.holo_last_error()
     assert lib.holo_debug_set_conv_tile(0) == 0
 
 

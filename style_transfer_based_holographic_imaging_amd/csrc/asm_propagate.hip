@@ -46,6 +46,9 @@ constexpr int kRowThreads = 256;
 // timing experiments of the row kernels (-DHOLO_DEBUG builds only, HOLO_ASM_ABLATE=<bits>; wrong results): K1: 4 no sincos,
 // 8 no FFT, 16 no transposed store, 32 no input loads; K3: 64 no loads, 128 no FFT, 256 no abs/angle, 512 no stores.
 // In the shipped build ASM_ABL() is the constant 0 and leaves no code behind.
+#ifndef HOLO_ASM_POLY_SINCOS
+#define HOLO_ASM_POLY_SINCOS 0   // 1: the Cody-Waite + polynomial sin/cos of rounds 1-3 for the field packing
+#endif
 #ifdef HOLO_DEBUG
 __device__ int g_asm_abl = 0;
 #define ASM_ABL(bit_) (g_asm_abl & (bit_))
@@ -69,17 +72,35 @@ __device__ __forceinline__ void sincos_poly(float r, int q, float* s, float* c) 
     *c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// sin/cos of the field's phase (Forward_model.py:22: amplitude * exp(1j * phase)): the hardware v_sin_f32 / v_cos_f32 take their
+// argument in REVOLUTIONS.  x / 2 pi is formed as a two-piece product (the fp32 constant and its remainder, the rounding of the
+// first product recovered with an FMA), reduced to [-0.5, 0.5] and handed to the hardware: measured max abs error 4.5e-7 on
+// [-8, 8] (scratch/sincos_probe.hip; the Cody-Waite + polynomial form it replaces: 1e-7) at 8 instructions instead of ~30 —
+// the forward row kernel's packing was 150 of its 500 instructions per lane.  Large arguments take the library path.
 __device__ __forceinline__ void sincos_f32(float x, float* s, float* c) {
     if (fabsf(x) > 8192.0f) {
         sincosf(x, s, c);
         return;
     }
+#if HOLO_ASM_POLY_SINCOS
     const float n = rintf(x * 0.63661977236758134f);
     float r = fmaf(-n, 1.5707963705062866f, x);
     r = fmaf(-n, -4.371138828673793e-08f, r);
     r = fmaf(-n, -1.7151245100058819e-15f, r);
     sincos_poly(r, (int)n & 3, s, c);
+#else
+    constexpr float kHi = 0.15915494309189533577f;                                       // fl32(1 / 2 pi)
+    constexpr float kLo = (float)(0.15915494309189533577 - (double)0.15915494309189533577f);
+    const float th = x * kHi;
+    const float tl = fmaf(x, kHi, -th) + x * kLo;
+    const float fr = (th - rintf(th)) + tl;
+    *s = __builtin_amdgcn_sinf(fr);
+    *c = __builtin_amdgcn_cosf(fr);
+#endif
 }
+
+// |o| through the hardware square root (v_sqrt_f32, 1 ulp) instead of the correctly rounded sqrtf (~10 instructions)
+__device__ __forceinline__ float amp_f32(v2f o) { return __builtin_amdgcn_sqrtf(o.x * o.x + o.y * o.y); }
 
 // atan2 for the phase output: octant reduction + an odd polynomial of degree 15 on [0,1] (Chebyshev-interpolated
 // atan(a)/a in a^2; max error 1.5e-7 rad evaluated in fp32 — the fp32 FFT noise on the phase is ~1e-6); the
@@ -87,7 +108,9 @@ __device__ __forceinline__ void sincos_f32(float x, float* s, float* c) {
 __device__ __forceinline__ float atan2_poly(float y, float x) {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float a = mx > 0.0f ? mn / mx : 0.0f;
+    // mn / mx through the hardware reciprocal (1 ulp) instead of the correctly rounded division (~10 instructions): the quotient
+    // carries ~1.5 ulp, below the polynomial's own 1.5e-7 rad
+    const float a = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
     const float s = a * a;
     float r = -0.00455979211255908f;
     r = fmaf(r, s, 0.023780519142746925f);
@@ -141,10 +164,13 @@ template <int P>
 __host__ __device__ constexpr int tw_entries_inv() { return fft_tw_total<P, +1>() > 0 ? fft_tw_total<P, +1>() : 1; }
 
 // ---- K1: pack + pad + row FFT ------------------------------------------------------------------
-template <int P, bool PAD>
+// IN_MODE is a COMPILE-TIME parameter: as a kernel argument every element's fetch sat behind a branch (complex: one 8-byte load,
+// amplitude / phase: two 4-byte loads) and hipcc waited vmcnt(0) after each one — a row's loads became E dependent round trips.
+template <int P, bool PAD, int IN_MODE>
 __global__ __launch_bounds__(kRowThreads) void asm_rows_fwd_kernel(
-    const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
+    const float* __restrict__ in0, const float* __restrict__ in1, long stride0, long stride1,
     float phase_scale, v2f* __restrict__ tbuf, long n_rows) {
+    constexpr int in_mode = IN_MODE;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = FftGeom<P>::G;       // lanes per row (<= one wave)
     constexpr int SEQ = kRowThreads / G;   // rows per block
@@ -321,7 +347,9 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
 // the memory phases of a tile overlap the arithmetic of its neighbour.  (At P = 512 the phases of the one-tile
 // blocks simply add up — 27 us copy skeleton + 23 us FFT passes + 6.5 us H = 58.5 us, ablation — but the
 // persistent form was not faster there.)
-template <int P, bool PAD>
+// SWEEP (n_dist > 1): a tile is (FIELD, column group); its columns are staged and forward-transformed once and the spectrum kept in
+// registers, then  H_d . IFFT . store  runs per distance (see asm_cols_t_kernel).
+template <int P, bool PAD, bool SWEEP>
 __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void asm_cols_persistent_kernel(
     const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const double* __restrict__ phase_const,
     int n_dist, int n_tiles, double inv_ppx, double lam2, double lamb, int ablate) {
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
     v2f pre[LD];
     int tile = blockIdx.x;
     if (tile < n_tiles) {
-        const v2f* src = tbuf + (long)(tile_fo(tile) / n_dist) * S * P + tile_kx0(tile);
+        const v2f* src = tbuf + (long)(SWEEP ? tile_fo(tile) : tile_fo(tile) / n_dist) * S * P + tile_kx0(tile);
 #pragma unroll
         for (int l = 0; l < LD; ++l) {
             const int i = tid + l * THREADS;
@@ -366,7 +394,7 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
         }
     }
     for (; tile < n_tiles; tile += gridDim.x) {
-        const int fo = tile_fo(tile), kx0 = tile_kx0(tile);
+        const int fo0 = SWEEP ? tile_fo(tile) * n_dist : tile_fo(tile), kx0 = tile_kx0(tile);
         // staged rows -> per-column sequences (compact: S entries, transposed; coalesced 128-B reads above)
 #pragma unroll
         for (int l = 0; l < LD; ++l) {
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
         if constexpr (C::PERSIST) {   // prefetch the next tile while this one is transformed
             const int nxt = tile + gridDim.x;
             if (nxt < n_tiles) {
-                const v2f* src = tbuf + (long)(tile_fo(nxt) / n_dist) * S * P + tile_kx0(nxt);
+                const v2f* src = tbuf + (long)(SWEEP ? tile_fo(nxt) : tile_fo(nxt) / n_dist) * S * P + tile_kx0(nxt);
 #pragma unroll
                 for (int l = 0; l < LD; ++l) {
                     const int i = tid + l * THREADS;
@@ -396,51 +424,66 @@ __global__ __launch_bounds__(ColCfg<P>::THREADS, ColCfg<P>::WAVES_PER_SIMD) void
         }
         if (!(ablate & 2)) fft_run<P, G, -1>(v, my, twf, t);   // spectrum in registers at ky = fft_elem_index<P,G,RL>(t,e)
 
-        // transfer function: one value per (column, |ky|), shared through LDS by rows ky and P-ky.  The column's
-        // LDS region is private to its G lanes (one wave or less): wave-local ordering, no block barrier.
-        fft_sync<G>();
-        {
-            // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
-            const double c_over_l = phase_const[fo] / lamb;
-            const int kx = kx0 + col;
-            const double fx = (double)(kx < P / 2 ? kx : kx - P) * inv_ppx;
-            const double fx2 = fx * fx;
-            for (int m = t; m <= P / 2; m += G) {
-                const double fy = (double)m * inv_ppx;
-                my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
+        v2f spec[SWEEP ? E : 1];
+        if constexpr (SWEEP) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) spec[e] = v[e];
+        }
+        const int d_count = SWEEP ? n_dist : 1;
+        for (int d = 0; d < d_count; ++d) {
+            const int fo = fo0 + d;
+            if (SWEEP && d > 0) {
+                __syncthreads();   // the previous distance's rows have left `cols`
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = spec[e];
             }
-        }
-        fft_sync<G>();
+            // transfer function: one value per (column, |ky|), shared through LDS by rows ky and P-ky.  The column's
+            // LDS region is private to its G lanes (one wave or less): wave-local ordering, no block barrier.
+            fft_sync<G>();
+            {
+                // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
+                const double c_over_l = phase_const[fo] / lamb;
+                const int kx = kx0 + col;
+                const double fx = (double)(kx < P / 2 ? kx : kx - P) * inv_ppx;
+                const double fx2 = fx * fx;
+                for (int m = t; m <= P / 2; m += G) {
+                    const double fy = (double)m * inv_ppx;
+                    my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
+                }
+            }
+            fft_sync<G>();
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int ky = fft_elem_index<P, G, RL>(t, e);
-            v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
-        }
-        if (!(ablate & 2)) fft_run<P, G, +1>(v, my, twi, t);
+            for (int e = 0; e < E; ++e) {
+                const int ky = fft_elem_index<P, G, RL>(t, e);
+                v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
+            }
+            if (!(ablate & 2)) fft_run<P, G, +1>(v, my, twi, t);
 
-        // keep the S centre rows; transpose back through LDS for a coalesced store
-        fft_sync<G>();
+            // keep the S centre rows; transpose back through LDS for a coalesced store
+            fft_sync<G>();
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = fft_elem_index<P, G, R1>(t, e);
-            const int y = PAD ? i - S / 2 : i;
-            if (y >= 0 && y < S) my[fft_pad(y)] = v[e];
-        }
-        __syncthreads();
-        v2f* dst = ubuf + (long)fo * S * P + kx0;
-        for (int i = tid; i < S * CW; i += THREADS) {
-            const int y = i / CW, cl = i % CW;
-            dst[(long)y * P + cl] = cols[cl * PITCH + fft_pad(y)];
+            for (int e = 0; e < E; ++e) {
+                const int i = fft_elem_index<P, G, R1>(t, e);
+                const int y = PAD ? i - S / 2 : i;
+                if (y >= 0 && y < S) my[fft_pad(y)] = v[e];
+            }
+            __syncthreads();
+            v2f* dst = ubuf + (long)fo * S * P + kx0;
+            for (int i = tid; i < S * CW; i += THREADS) {
+                const int y = i / CW, cl = i % CW;
+                dst[(long)y * P + cl] = cols[cl * PITCH + fft_pad(y)];
+            }
         }
         __syncthreads();   // the next tile's staging overwrites `cols`
     }
 }
 
 // ---- K3: row IFFT + crop + epilogue ---------------------------------------------------------------
-template <int P, bool PAD>
+template <int P, bool PAD, int OUT_MODE>   // OUT_MODE at compile time: the epilogue is straight-line code per element
 __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
-    const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode,
+    const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1,
     long ostride0, long ostride1, long n_rows, float scale) {
+    constexpr int out_mode = OUT_MODE;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = FftGeom<P>::G;
     constexpr int SEQ = kRowThreads / G;
@@ -480,10 +523,10 @@ __global__ __launch_bounds__(kRowThreads) void asm_rows_inv_kernel(
             const v2f o = v[e] * scale;
             const long pix = (long)y * S + x;
             if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
-                out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
+                out0[fo * ostride0 + pix] = amp_f32(o);
                 out1[fo * ostride1 + pix] = atan2_poly(o.y, o.x);
             } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
-                const float a = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
+                const float a = amp_f32(o);  // Forward_model.py:39: pow(abs(.),2)
                 out0[fo * ostride0 + pix] = a * a;
             } else {
                 reinterpret_cast<v2f*>(out0)[fo * ostride0 + pix] = o;
@@ -551,12 +594,13 @@ __device__ __forceinline__ int htab_uid_wave(const double* __restrict__ phase_co
     return m ? __ffsll((long long)m) - 1 : (fo < kHSlots ? fo : -1);
 }
 
-template <int P, bool PAD>
+template <int P, bool PAD, int IN_MODE>
 __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_entries_fwd<P>())) void asm_rows_fwd_t_kernel(
-    const float* __restrict__ in0, const float* __restrict__ in1, int in_mode, long stride0, long stride1,
+    const float* __restrict__ in0, const float* __restrict__ in1, long stride0, long stride1,
     float phase_scale, v2f* __restrict__ tbuf, int tab_blocks, v2f* __restrict__ htab,
     const double* __restrict__ phase_const, int n_out, double inv_ppx, double lam2, double lamb, int n_row_tiles) {
     using C = RowTCfg<P>;
+    constexpr int in_mode = IN_MODE;   // compile-time: see asm_rows_fwd_kernel
     if ((int)blockIdx.x < tab_blocks) {
         // table blocks (dispatched FIRST, so that they run beside the row blocks instead of forming a tail): block j computes
         // entries [j*THREADS, (j+1)*THREADS) of EVERY slot that represents itself (usually one).  The constants of the slots
@@ -716,8 +760,12 @@ struct ColTCfg {
 };
 
 // K2: one column per G lanes, global -> registers -> global
-template <int P, bool PAD>
-__global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) void asm_cols_t_kernel(
+// SWEEP (n_dist > 1; the reference idiom repeats a field against a list of distances, utils/Data_loader.py:59-62): a block owns a
+// FIELD's columns, loads and forward-transforms them ONCE, keeps the spectrum in registers and runs  H_d . IFFT . store  per
+// distance — instead of n_dist loads and forward transforms of the same column.  Same instruction sequence per output: bit-identical
+// to the one-distance form.
+template <int P, bool PAD, bool SWEEP>
+__global__ __launch_bounds__(ColTCfg<P>::THREADS, SWEEP ? (ColTCfg<P>::WAVES_PER_SIMD > 4 ? 4 : ColTCfg<P>::WAVES_PER_SIMD) : ColTCfg<P>::WAVES_PER_SIMD) void asm_cols_t_kernel(
     const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const double* __restrict__ phase_const,
     int n_dist, double inv_ppx, double lam2, double lamb, int ablate, const v2f* __restrict__ htab) {
     using C = ColTCfg<P>;
@@ -734,15 +782,15 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) vo
     __shared__ int s_uid;
 
     const int tid = threadIdx.x;
-    const int fo = blockIdx.y;          // output field = field * n_dist + dist
-    const int f = fo / n_dist;
+    // one-distance form: blockIdx.y = output field (= field * n_dist + dist); SWEEP: blockIdx.y = field, distances looped below
+    const int f = SWEEP ? (int)blockIdx.y : (int)blockIdx.y / n_dist;
     const int col = tid / G, t = tid % G;
     const int kx = blockIdx.x * CW + col;
     v2f* my = cols + col * PITCH;
     fft_fill_twiddles<P, -1>(twf, tid, THREADS);
     if (!SYM) fft_fill_twiddles<P, +1>(twi, tid, THREADS);
-    if (tid < 64) {   // THREADS >= 64 for every P of this path except the smallest, which skips the table
-        const int u = (THREADS >= 64 && htab != nullptr) ? htab_uid_wave(phase_const, fo, tid) : -1;
+    if (!SWEEP && tid < 64) {   // THREADS >= 64 for every P of this path except the smallest, which skips the table
+        const int u = (THREADS >= 64 && htab != nullptr) ? htab_uid_wave(phase_const, (int)blockIdx.y, tid) : -1;
         if (tid == 0) s_uid = u;
     }
 
@@ -771,55 +819,77 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, ColTCfg<P>::WAVES_PER_SIMD) vo
     __syncthreads();  // twiddle tables: the only block barrier
     if (!(ablate & 2)) fft_run<P, G, -1>(v, my, twf, t);   // spectrum in registers at ky = fft_elem_index<P,G,RL>(t,e)
 
-    const int uid = s_uid;   // written before the twiddle barrier above
-    if (uid >= 0) {
-        // transfer function from this distance's table: the column's |ky| values are contiguous
-        const v2f* __restrict__ hcol = htab + (size_t)uid * htab_elems<P>() + (size_t)(kx <= P / 2 ? kx : P - kx) * (P / 2 + 1);
+    v2f spec[SWEEP ? E : 1];
+    if constexpr (SWEEP) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int ky = fft_elem_index<P, G, RL>(t, e);
-            v[e] = cmul(v[e], hcol[ky <= P / 2 ? ky : P - ky]);
+        for (int e = 0; e < E; ++e) spec[e] = v[e];
+    }
+    const int d_count = SWEEP ? n_dist : 1;
+    for (int d = 0; d < d_count; ++d) {
+        const int fo = SWEEP ? f * n_dist + d : (int)blockIdx.y;
+        int uid;
+        if constexpr (SWEEP) {
+            // every wave finds the slot itself (a wave is 64 lanes here: THREADS >= 64 wherever a table exists)
+            uid = (THREADS >= 64 && htab != nullptr) ? htab_uid_wave(phase_const, fo, tid & 63) : -1;
+            uid = __builtin_amdgcn_readfirstlane(uid);
+            if (d > 0) {
+                fft_sync<G>();    // the inverse transform of the previous distance is done with the column's LDS region
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = spec[e];
+            }
+        } else {
+            uid = s_uid;   // written before the twiddle barrier above
         }
-    } else {
-        // no table slot (more than kHSlots distinct distances in the call): one value per (column, |ky|), shared through
-        // LDS by rows ky and P-ky.  The column's LDS region is private to its G lanes: wave-local ordering, no block barrier.
-        fft_sync<G>();
-        {
-            // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
-            const double c_over_l = phase_const[fo] / lamb;
-            const double fx = (double)(kx <= P / 2 ? kx : P - kx) * inv_ppx;
-            const double fx2 = fx * fx;
-            for (int m = t; m <= P / 2; m += G) {
-                const double fy = (double)m * inv_ppx;
-                my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
+        if (uid >= 0) {
+            // transfer function from this distance's table: the column's |ky| values are contiguous
+            const v2f* __restrict__ hcol = htab + (size_t)uid * htab_elems<P>() + (size_t)(kx <= P / 2 ? kx : P - kx) * (P / 2 + 1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int ky = fft_elem_index<P, G, RL>(t, e);
+                v[e] = cmul(v[e], hcol[ky <= P / 2 ? ky : P - ky]);
+            }
+        } else {
+            // no table slot (more than kHSlots distinct distances in the call): one value per (column, |ky|), shared through
+            // LDS by rows ky and P-ky.  The column's LDS region is private to its G lanes: wave-local ordering, no block barrier.
+            fft_sync<G>();
+            {
+                // squared signed frequencies (k/(P*px))^2: numpy divides by S*px, here k * (1/(P*px)) — 1e-16 relative apart
+                const double c_over_l = phase_const[fo] / lamb;
+                const double fx = (double)(kx <= P / 2 ? kx : P - kx) * inv_ppx;
+                const double fx2 = fx * fx;
+                for (int m = t; m <= P / 2; m += G) {
+                    const double fy = (double)m * inv_ppx;
+                    my[m] = (ablate & 1) ? v2f{1.f, 0.f} : transfer_value(fx2 + fy * fy, lam2, c_over_l);
+                }
+            }
+            fft_sync<G>();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int ky = fft_elem_index<P, G, RL>(t, e);
+                v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
             }
         }
-        fft_sync<G>();
+        if (!(ablate & 2)) fft_run<P, G, +1>(v, my, twi, t);
+
+        // keep the S centre rows: contiguous runs of G values per register slot
+        v2f* dst = ubuf + ((long)fo * P + kx) * S;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int ky = fft_elem_index<P, G, RL>(t, e);
-            v[e] = cmul(v[e], my[ky <= P / 2 ? ky : P - ky]);
+            const int r = e % R1;
+            if (PAD && ((r + 1) * 4 <= R1 || r * 4 >= 3 * R1)) continue;
+            const int i = fft_elem_index<P, G, R1>(t, e);
+            dst[PAD ? i - S / 2 : i] = v[e];
         }
-    }
-    if (!(ablate & 2)) fft_run<P, G, +1>(v, my, twi, t);
-
-    // keep the S centre rows: contiguous runs of G values per register slot
-    v2f* dst = ubuf + ((long)fo * P + kx) * S;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int r = e % R1;
-        if (PAD && ((r + 1) * 4 <= R1 || r * 4 >= 3 * R1)) continue;
-        const int i = fft_elem_index<P, G, R1>(t, e);
-        dst[PAD ? i - S / 2 : i] = v[e];
     }
 }
 
 // K3: 16 rows of one output field: transposed load, row IFFT, crop, epilogue
-template <int P, bool PAD>
+template <int P, bool PAD, int OUT_MODE>
 __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_entries_inv<P>())) void asm_rows_inv_t_kernel(
-    const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1, int out_mode,
+    const v2f* __restrict__ ubuf, float* __restrict__ out0, float* __restrict__ out1,
     long ostride0, long ostride1, float scale, int n_tiles) {
     using C = RowTCfg<P>;
+    constexpr int out_mode = OUT_MODE;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
     constexpr int R1 = fft_radix<P, +1>(0);
@@ -893,10 +963,10 @@ __global__ __launch_bounds__(RowTCfg<P>::THREADS, RowTCfg<P>::waves_per_simd(tw_
                     out0[fo * ostride0 + pix] = o.x;
                     out1[fo * ostride1 + pix] = o.y;
                 } else if (out_mode == HOLO_ASM_OUT_AMP_PHASE) {
-                    out0[fo * ostride0 + pix] = sqrtf(o.x * o.x + o.y * o.y);
+                    out0[fo * ostride0 + pix] = amp_f32(o);
                     out1[fo * ostride1 + pix] = atan2_poly(o.y, o.x);
                 } else if (out_mode == HOLO_ASM_OUT_INTENSITY) {
-                    const float a = sqrtf(o.x * o.x + o.y * o.y);  // Forward_model.py:39: pow(abs(.),2)
+                    const float a = amp_f32(o);  // Forward_model.py:39: pow(abs(.),2)
                     out0[fo * ostride0 + pix] = a * a;
                 } else {
                     reinterpret_cast<v2f*>(out0)[fo * ostride0 + pix] = o;
@@ -959,25 +1029,44 @@ static int launch_asm(const AsmArgs& a) {
         {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_kernel<P, PAD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_persistent_kernel<P, PAD>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_persistent_kernel<P, PAD, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_persistent_kernel<P, PAD, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
         }
-        if (row_lds_f > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_kernel<P, PAD>),
+        if (row_lds_f > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_kernel<P, PAD, HOLO_ASM_IN_AMP_PHASE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_f);
-        if (row_lds_i > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_kernel<P, PAD>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_kernel<P, PAD, HOLO_ASM_IN_COMPLEX>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_f);
+        }
+        if (row_lds_i > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_kernel<P, PAD, HOLO_ASM_OUT_AMP_PHASE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_kernel<P, PAD, HOLO_ASM_OUT_INTENSITY>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_kernel<P, PAD, HOLO_ASM_OUT_COMPLEX>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
+        }
     });
     const long rows_in = (long)a.n_fields * S;
-    hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kRowThreads),
-                       row_lds_f, a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale,
-                       reinterpret_cast<v2f*>(a.tbuf), rows_in);
+    if (a.in_mode == HOLO_ASM_IN_COMPLEX)
+        hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD, HOLO_ASM_IN_COMPLEX>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kRowThreads),
+                           row_lds_f, a.stream, a.in0, a.in1, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf), rows_in);
+    else
+        hipLaunchKernelGGL((asm_rows_fwd_kernel<P, PAD, HOLO_ASM_IN_AMP_PHASE>), dim3((unsigned)((rows_in + SEQ - 1) / SEQ)), dim3(kRowThreads),
+                           row_lds_f, a.stream, a.in0, a.in1, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf), rows_in);
     {
         const long n_tiles = (long)(P / C::CW) * a.n_fields * a.n_dist;
-        if (C::PERSIST) {   // one block per CU, grid-stride over the tiles
+        if (C::PERSIST && a.n_dist > 1) {   // a sweep: tiles are (field, column group), the distances looped inside on the shared spectrum
+            const long f_tiles = (long)(P / C::CW) * a.n_fields;
+            const unsigned grid = (unsigned)(f_tiles < 256 ? f_tiles : 256);
+            hipLaunchKernelGGL((asm_cols_persistent_kernel<P, PAD, true>), dim3(grid), dim3(C::THREADS), col_lds, a.stream,
+                               reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const,
+                               a.n_dist, (int)f_tiles, 1.0 / a.ppx, a.lam2, a.lamb, a.ablate);
+        } else if (C::PERSIST) {   // one block per CU, grid-stride over the tiles
             const unsigned grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
-            hipLaunchKernelGGL((asm_cols_persistent_kernel<P, PAD>), dim3(grid), dim3(C::THREADS), col_lds, a.stream,
+            hipLaunchKernelGGL((asm_cols_persistent_kernel<P, PAD, false>), dim3(grid), dim3(C::THREADS), col_lds, a.stream,
                                reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const,
                                a.n_dist, (int)n_tiles, 1.0 / a.ppx, a.lam2, a.lamb, a.ablate);
         } else {
@@ -988,9 +1077,13 @@ static int launch_asm(const AsmArgs& a) {
     }
     const long rows_out = rows_in * a.n_dist;
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
-    hipLaunchKernelGGL((asm_rows_inv_kernel<P, PAD>), dim3((unsigned)((rows_out + SEQ - 1) / SEQ)), dim3(kRowThreads),
-                       row_lds_i, a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0,
-                       a.os1, rows_out, scale);
+#define HOLO_LAUNCH_INV(mode_)                                                                                              \
+    hipLaunchKernelGGL((asm_rows_inv_kernel<P, PAD, mode_>), dim3((unsigned)((rows_out + SEQ - 1) / SEQ)), dim3(kRowThreads), \
+                       row_lds_i, a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.os0, a.os1, rows_out, scale)
+    if (a.out_mode == HOLO_ASM_OUT_AMP_PHASE) HOLO_LAUNCH_INV(HOLO_ASM_OUT_AMP_PHASE);
+    else if (a.out_mode == HOLO_ASM_OUT_INTENSITY) HOLO_LAUNCH_INV(HOLO_ASM_OUT_INTENSITY);
+    else HOLO_LAUNCH_INV(HOLO_ASM_OUT_COMPLEX);
+#undef HOLO_LAUNCH_INV
     return check_launch("holo_asm_propagate");
 }
 
@@ -1004,14 +1097,26 @@ static int launch_asm_t(const AsmArgs& a) {
     static DeviceOnce attr_once;  // per device, published after the attributes are set
     attr_once.run([&] {
         if (C::LDS > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_t_kernel<P, PAD>),
+        {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_t_kernel<P, PAD, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
-        if (row_lds_f > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_t_kernel<P, PAD>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_cols_t_kernel<P, PAD, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        }
+        if (row_lds_f > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_t_kernel<P, PAD, HOLO_ASM_IN_AMP_PHASE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_f);
-        if (row_lds_i > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_t_kernel<P, PAD>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_fwd_t_kernel<P, PAD, HOLO_ASM_IN_COMPLEX>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_f);
+        }
+        if (row_lds_i > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_t_kernel<P, PAD, HOLO_ASM_OUT_AMP_PHASE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_t_kernel<P, PAD, HOLO_ASM_OUT_INTENSITY>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&asm_rows_inv_t_kernel<P, PAD, HOLO_ASM_OUT_COMPLEX>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds_i);
+        }
     });
     const long blocks_in = (long)a.n_fields * S / kTileRows;
     // transfer-function tables: extra blocks of the row kernel (blocks of the smallest grids have fewer than 64 threads: no table)
@@ -1023,21 +1128,34 @@ static int launch_asm_t(const AsmArgs& a) {
     // persistent row blocks: as many as are resident at once (LDS / wave limit), each walking tiles with that stride
     const long fwd_slots = (long)device_cus() * R::bpc(tw_entries_fwd<P>());
     const long fwd_grid = (HOLO_ASM_PERSIST_FWD && blocks_in > fwd_slots) ? fwd_slots : blocks_in;
-    hipLaunchKernelGGL((asm_rows_fwd_t_kernel<P, PAD>), dim3((unsigned)(fwd_grid + tab_blocks)), dim3(R::THREADS), row_lds_f,
-                       a.stream, a.in0, a.in1, a.in_mode, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf),
-                       (int)tab_blocks, reinterpret_cast<v2f*>(a.htab), a.phase_const, n_out, 1.0 / a.ppx, a.lam2, a.lamb,
-                       (int)blocks_in);
-    hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD>), dim3(P / C::CW, n_out), dim3(C::THREADS), C::LDS, a.stream,
-                       reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
-                       1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr);
+#define HOLO_LAUNCH_FWD(mode_)                                                                                              \
+    hipLaunchKernelGGL((asm_rows_fwd_t_kernel<P, PAD, mode_>), dim3((unsigned)(fwd_grid + tab_blocks)), dim3(R::THREADS), row_lds_f, \
+                       a.stream, a.in0, a.in1, a.s0, a.s1, a.phase_scale, reinterpret_cast<v2f*>(a.tbuf),                   \
+                       (int)tab_blocks, reinterpret_cast<v2f*>(a.htab), a.phase_const, n_out, 1.0 / a.ppx, a.lam2, a.lamb,   \
+                       (int)blocks_in)
+    if (a.in_mode == HOLO_ASM_IN_COMPLEX) HOLO_LAUNCH_FWD(HOLO_ASM_IN_COMPLEX);
+    else HOLO_LAUNCH_FWD(HOLO_ASM_IN_AMP_PHASE);
+#undef HOLO_LAUNCH_FWD
+    if (a.n_dist > 1)    // a sweep: one block per (field, column group), the distances looped inside on the shared spectrum
+        hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD, true>), dim3(P / C::CW, a.n_fields), dim3(C::THREADS), C::LDS, a.stream,
+                           reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
+                           1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr);
+    else
+        hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD, false>), dim3(P / C::CW, n_out), dim3(C::THREADS), C::LDS, a.stream,
+                           reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
+                           1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr);
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
     const long tiles_out = blocks_in * a.n_dist;
     const long inv_slots = (long)device_cus() * R::bpc(tw_entries_inv<P>());
     // measured (64 fields): P = 1024: 35.5 -> 30.4 us with the persistent grid, P = 512: 23.0 -> 24.3 (one tile per block there)
     const long inv_grid = (HOLO_ASM_PERSIST_ROWS && P >= 1024 && tiles_out > inv_slots) ? inv_slots : tiles_out;
-    hipLaunchKernelGGL((asm_rows_inv_t_kernel<P, PAD>), dim3((unsigned)inv_grid), dim3(R::THREADS), row_lds_i,
-                       a.stream, reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.out_mode, a.os0, a.os1, scale,
-                       (int)tiles_out);
+#define HOLO_LAUNCH_INV(mode_)                                                                                              \
+    hipLaunchKernelGGL((asm_rows_inv_t_kernel<P, PAD, mode_>), dim3((unsigned)inv_grid), dim3(R::THREADS), row_lds_i, a.stream, \
+                       reinterpret_cast<const v2f*>(a.ubuf), a.out0, a.out1, a.os0, a.os1, scale, (int)tiles_out)
+    if (a.out_mode == HOLO_ASM_OUT_AMP_PHASE) HOLO_LAUNCH_INV(HOLO_ASM_OUT_AMP_PHASE);
+    else if (a.out_mode == HOLO_ASM_OUT_INTENSITY) HOLO_LAUNCH_INV(HOLO_ASM_OUT_INTENSITY);
+    else HOLO_LAUNCH_INV(HOLO_ASM_OUT_COMPLEX);
+#undef HOLO_LAUNCH_INV
     return check_launch("holo_asm_propagate");
 }
 

@@ -355,6 +355,240 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv3x3_b16_kerne
 #undef B16_WAIT_N
 #undef B16_PLAN
 
+// ReLU, optional 2x2 max-pool, bf16 and the 16-byte NHWC stores of one wave's 64 pixels x (16 * WTN) channels (the accumulators
+// already hold the bias: they start from it): tile (mt, nt): lane (p, h = lane >> 4) holds channels nt*16 + 4h .. 4h+3 of its pixel;
+// v_permlane16_swap joins the quads of a pair of channel tiles into 16-byte runs.
+template <int WTN>
+__device__ __forceinline__ void b16_store_tile(f32x4 (&acc)[4][WTN], const B16Tile& cur,
+                                               b16_t* __restrict__ y, int H, int W, int Cout, int relu, int pool, int p, int ku,
+                                               int lpx, int lpy, int cwave) {
+    const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+    const float fl = relu ? 0.0f : -__builtin_inff();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int X = cur.x0 + lpx + (mt & 1) * 8, Y = cur.y0 + lpy + (mt >> 1) * 2;
+        const bool inside = X < W && Y < H;
+        bool writer = inside;
+        size_t pix;
+        b16_t* __restrict__ yimg;
+        if (!pool) {
+            yimg = y + (size_t)cur.img * H * W * Cout;
+            pix = (size_t)Y * W + X;
+        } else {
+            yimg = y + (size_t)cur.img * Ho * Wo * Cout;
+            writer = inside && (p & 3) == 0;          // the window's top-left pixel stores
+            pix = (size_t)(Y >> 1) * Wo + (X >> 1);
+        }
+#pragma unroll
+        for (int nt = 0; nt < WTN; nt += 2) {
+            unsigned pk[2][2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                // the bias is already in the accumulators (they start from it); ReLU as a max against 0 | -inf (no branch)
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[mt][nt + h2][i], fl);
+                if (pool) {   // MaxPool2d(2,2,ceil_mode=True): window = lanes 4g..4g+3; members beyond the image edge count as 0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float s = inside ? v[i] : 0.0f;
+                        s = fmaxf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true)));
+                        s = fmaxf(s, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true)));
+                        v[i] = s;
+                    }
+                }
+                typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+                const b16x2 lo = {(b16_t)v[0], (b16_t)v[1]}, hi = {(b16_t)v[2], (b16_t)v[3]};
+                pk[h2][0] = __builtin_bit_cast(unsigned, lo);
+                pk[h2][1] = __builtin_bit_cast(unsigned, hi);
+            }
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[1][0], pk[0][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[1][1], pk[0][1], false, false);
+            const uint4 run = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            const int ch = cwave + nt * 16 + ((ku & 1) ? 0 : 16) + (ku >> 1) * 8;
+            if (writer) *reinterpret_cast<uint4*>(yimg + pix * Cout + ch) = run;
+        }
+    }
+}
+
+// ================================================================================================================
+// Weights-resident kernel for the 64 -> 64 layers (net.py:80 enc_2's first conv, net.py:66,69 the decoder's full-resolution pair):
+// they are 20 % of the network's FLOP and its most memory-bound convolutions (128 B in + 128 B out per pixel for 73.7 kFLOP).
+// All 2 x 9 weight tiles (72 KB) stay in LDS for the life of a persistent block, so the only staging left is the halo — one
+// 32-channel chunk (39 KB) per 144 MFMAs of each wave — and the block meets at a barrier twice per 512-pixel tile instead of six
+// times.  The two halo buffers hold chunk 0 and chunk 1: phase 0 of tile i (reads buffer 0) stages chunk 1 of tile i into buffer 1,
+// which phase 1 of tile i - 1 has just left; phase 1 of tile i (reads buffer 1) stages chunk 0 of tile i + 1 into buffer 0.
+// ================================================================================================================
+struct B16W {
+    static constexpr int THREADS = 512, WTN = 4;
+    static constexpr int PR = 32, HR = PR + 2;
+    static constexpr int A_UNITS = HR * kB16HW * 4;
+    static constexpr int A_ROUNDS = (A_UNITS + THREADS - 1) / THREADS;     // 5
+    static constexpr int A_BYTES = A_ROUNDS * THREADS * 16;                // padded to whole rounds (uniform load counts)
+    static constexpr int W_TILE = 64 * 64;                                 // one (chunk, tap): 64 channels x 64 bytes
+    static constexpr int W_BYTES = 18 * W_TILE;
+    static constexpr int W_ROUNDS = W_BYTES / 16 / THREADS;                // 9
+    static constexpr int LDS_BYTES = W_BYTES + 2 * A_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+__global__ __launch_bounds__(512, 2) void conv3x3_b16_wres_kernel(
+    const b16_t* __restrict__ x, const b16_t* __restrict__ wp, const float* __restrict__ bias, b16_t* __restrict__ y,
+    int H, int W, int tiles_x, int tiles_y, int total_tiles, int relu, int pool) {
+    using C = B16W;
+    constexpr int Cin = 64, Cout = 64, WTN = C::WTN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_w = smem;                   // [2 chunks][9 taps][64 co][64 B]
+    unsigned char* lds_a = smem + C::W_BYTES;      // [2 chunks][A_BYTES]
+    const int tid = threadIdx.x;
+    int first = blockIdx.x;
+    if ((gridDim.x & 7) == 0) first = (first & 7) * (gridDim.x >> 3) + (first >> 3);
+    if (first >= total_tiles) return;
+    const size_t img_elems = (size_t)H * W * Cin;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_hi = __builtin_amdgcn_readfirstlane(wave >= 4 ? 1 : 0);
+    const int wave_base = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+    const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
+#define B16W_GLDS(sbase_, voff_, ldst_)                                                                     \
+    {                                                                                                      \
+        unsigned m0_keep;                                                                                  \
+        const unsigned lds_u = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(ldst_));               \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t" \
+                     "s_mov_b32 m0, %0"                                                                     \
+                     : "=&s"(m0_keep)                                                                      \
+                     : "v"(voff_), "s"(sbase_), "s"(lds_u)                                                 \
+                     : "memory");                                                                          \
+    }
+#define B16W_PLAN(dst_, tile_)                                                                             \
+    _Pragma("unroll") for (int r = 0; r < C::A_ROUNDS; ++r) {                                              \
+        const int u = tid + r * C::THREADS;                                                                \
+        const int q = u < C::A_UNITS ? u >> 2 : 0;            /* padding lanes: a valid dummy source */    \
+        const int hy = q / kB16HW, hx = q % kB16HW;                                                        \
+        const int ry = reflect1((tile_).y0 - 1 + hy, H);                                                   \
+        const int rx = reflect1((tile_).x0 - 1 + hx, W);                                                   \
+        dst_[r] = (unsigned)((ry * W + rx) * Cin + 8 * ((u & 3) ^ b16_swz_a(hx))) * 2u;                    \
+    }
+#define B16W_LOAD_A1(r_, xchunk_, buf_) B16W_GLDS((xchunk_), a_pl[r_], C::W_BYTES + (buf_) * C::A_BYTES + (r_) * C::THREADS * 16 + wave_base)
+
+    // ---- the weights, once: packed [chunk][tap][co][32] = 18 tiles of 4 KB, contiguous; unit swizzle as in the staged kernel ----
+#pragma unroll
+    for (int r = 0; r < C::W_ROUNDS; ++r) {
+        const int u = tid + r * C::THREADS;
+        const int tile = u >> 8, v = u & 255;                 // 256 units per (chunk, tap) tile
+        const int co = v >> 2, c = (v & 3) ^ b16_swz_b(co);
+        const int src = tile * C::W_TILE + (co * kB16KC + 8 * c) * 2;
+        B16W_GLDS(wp, src, r * C::THREADS * 16 + wave_base)
+    }
+    const int p = lane & 15, ku = lane >> 4;
+    const int lpx = (p & 1) | ((p >> 2) << 1);
+    const int lpy = wave * 4 + ((p >> 1) & 1);
+    const int b_off0 = p * 64 + ((ku ^ b16_swz_b(p)) << 4);
+    int a_lane[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) a_lane[dx] = (lpy * kB16HW + lpx) * 64 + ((ku ^ b16_swz_a(lpx + dx)) << 4);
+
+    f32x4 biasq[WTN];
+#pragma unroll
+    for (int nt = 0; nt < WTN; ++nt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + nt * 16 + 4 * ku);
+        biasq[nt] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+    B16Tile cur = b16_decode(first, 1, tiles_x, tiles_y, C::PR, 64);
+    unsigned a_pl[C::A_ROUNDS];            // halo staging plan of the tile whose chunks are staged next
+    B16W_PLAN(a_pl, cur)
+    {
+        const b16_t* x0p = x + cur.img * img_elems;
+#pragma unroll
+        for (int r = 0; r < C::A_ROUNDS; ++r) { B16W_LOAD_A1(r, x0p, 0) }
+#pragma unroll
+        for (int r = 0; r < C::A_ROUNDS; ++r) { B16W_LOAD_A1(r, x0p + kB16KC, 1) }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = first; t < total_tiles; t += gridDim.x) {
+        const bool more_tiles = t + (int)gridDim.x < total_tiles;
+        const B16Tile nxt = b16_decode(more_tiles ? t + (int)gridDim.x : t, 1, tiles_x, tiles_y, C::PR, 64);
+        const b16_t* __restrict__ xcur = x + cur.img * img_elems;
+        const b16_t* __restrict__ xnxt = x + nxt.img * img_elems;
+        f32x4 acc[4][WTN];      // start from the bias (channels nt*16 + 4*ku .. +3 of this lane): the epilogue has nothing to add
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WTN; ++nt) acc[mt][nt] = biasq[nt];
+
+#pragma unroll
+        for (int chunk = 0; chunk < 2; ++chunk) {
+            // chunk phase: 9 taps x WTN channel tiles = 36 groups of 4 MFMAs; weight fragments two groups ahead, pixel fragments one
+            // tap ahead; the phase's 5 halo loads go one at a time behind groups 2, 6, 10, ... (+ 1 in the upper waves)
+            const unsigned char* abuf = lds_a + chunk * C::A_BYTES;
+            const unsigned char* wbuf = lds_w + chunk * 9 * C::W_TILE;
+            if (chunk == 1 && more_tiles) { B16W_PLAN(a_pl, nxt) }     // phase 0 staged with the current tile's plan; from here on the next tile's
+            const bool dma = !(HOLO_B16_ABLATE & 1) && (chunk == 0 ? t != first : more_tiles);
+            const b16_t* xdma = chunk == 0 ? xcur + kB16KC : xnxt;      // phase 0: this tile's chunk 1 -> buffer 1; phase 1: next tile's chunk 0 -> buffer 0
+            b16x8 afr[2][4], bfr[3];
+#define B16W_READ_A(tap_, mt_) *reinterpret_cast<const b16x8*>(abuf + a_lane[(tap_) % 3] + ((((mt_) >> 1) * 2 + (tap_) / 3) * kB16HW + ((mt_) & 1) * 8 + (tap_) % 3) * 64)
+#define B16W_READ_B(tap_, nt_) *reinterpret_cast<const b16x8*>(wbuf + (tap_) * C::W_TILE + b_off0 + (nt_) * 1024)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) afr[0][mt] = B16W_READ_A(0, mt);
+            bfr[0] = B16W_READ_B(0, 0);
+            bfr[1] = B16W_READ_B(0, 1);
+#pragma unroll
+            for (int g = 0; g < 9 * WTN; ++g) {
+                const int tap = g / WTN, nt = g % WTN;
+#pragma unroll
+                for (int k = 0; k < C::A_ROUNDS; ++k) {
+                    if (g == 2 + 4 * k || g == 3 + 4 * k) {
+                        if (wave_hi == (g - 2 - 4 * k)) {
+                            if (dma) { B16W_LOAD_A1(k, xdma, chunk ^ 1) }
+                        }
+                    }
+                }
+                if (g + 2 < 9 * WTN) bfr[(g + 2) % 3] = B16W_READ_B((g + 2) / WTN, (g + 2) % WTN);
+                if (tap < 8) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        if (nt == mt) afr[(tap + 1) & 1][mt] = B16W_READ_A(tap + 1, mt);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[g % 3], afr[tap & 1][mt], acc[mt][nt], 0, 0, 0);
+            }
+#undef B16W_READ_A
+#undef B16W_READ_B
+            if (!(HOLO_B16_ABLATE & 2) && (chunk == 0 || more_tiles)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this phase's halo loads (and the previous tile's stores) are done
+                __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this phase's fragment reads are done
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        b16_store_tile<WTN>(acc, cur, y, H, W, Cout, relu, pool, p, ku, lpx, lpy, 0);
+        cur = nxt;
+    }
+}
+#undef B16W_GLDS
+#undef B16W_PLAN
+#undef B16W_LOAD_A1
+
+static int launch_conv_b16_wres(const b16_t* x, const b16_t* wp, const float* bias, b16_t* y, int batch, int h, int w, int relu, int pool,
+                                hipStream_t stream) {
+    using C = B16W;
+    const int tiles_x = ceil_div(w, 16), tiles_y = ceil_div(h, C::PR);
+    const long tiles = (long)batch * tiles_x * tiles_y;
+    HOLO_REQUIRE(tiles > 0 && tiles < 2147483647L, HOLO_ERR_UNSUPPORTED, "conv: %ld tiles", tiles);
+    static DeviceOnce attr_once;
+    attr_once.run([] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_b16_wres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+    });
+    const long cus = device_cus();
+    const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
+    hipLaunchKernelGGL(conv3x3_b16_wres_kernel, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, x, wp, bias, y, h, w, tiles_x, tiles_y,
+                       (int)tiles, relu, pool);
+    return check_launch("holo_conv3x3_bf16");
+}
+
 template <int WM, int WN, int WTN>
 static int launch_conv_b16(const b16_t* x, const b16_t* wp, const float* bias, b16_t* y, int batch, int h, int w, int cin, int cout,
                            int relu, int pool, hipStream_t stream) {
@@ -380,8 +614,8 @@ int conv3x3_b16_try(const void* x, const void* wp, const float* bias, void* y, i
     const b16_t* xb = static_cast<const b16_t*>(x);
     const b16_t* wb = static_cast<const b16_t*>(wp);
     b16_t* yb = static_cast<b16_t*>(y);
-    (void)variant;
     if (cin % 32 != 0) return -1;
+    if (variant == 3) return (cin == 64 && cout == 64) ? launch_conv_b16_wres(xb, wb, bias, yb, batch, h, w, relu, pool, stream) : -1;
     if (cout % 128 == 0) return launch_conv_b16<8, 1, 8>(xb, wb, bias, yb, batch, h, w, cin, cout, relu, pool, stream);   // 512 px x 128 co
     if (cout % 64 == 0) return launch_conv_b16<8, 1, 4>(xb, wb, bias, yb, batch, h, w, cin, cout, relu, pool, stream);    // 512 px x 64 co
     return -1;

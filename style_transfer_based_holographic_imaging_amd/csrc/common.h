@@ -67,6 +67,12 @@ inline int device_cus() {
     return cus;
 }
 
+// Kernels whose summation grouping differs from the standard family (fp32 rounding of partial sums: not bit-identical to it) are
+// chosen from PER-IMAGE quantities, and only for batches in the open-ended batch bucket (engine.Plan.BATCH_TOPS: 1 | 2 | 3-5 | 6-8 |
+// 9-12 | 13+): a hologram's arithmetic then does not depend on the batch it arrives in within a bucket, and all batches >= 13 — every
+// shard of a multi-GPU job, every micro-batch of a fixed-total pass — take the same kernels.
+constexpr int kOpenBatchBucket = 13;
+
 // tile selection of the 3x3 / transposed convolutions: 0 = automatic (shipped), 1..3 force a variant (holo_debug_set_conv_tile,
 // used by the tests that hold the variants bit-identical)
 int conv_tile_override();

@@ -608,6 +608,139 @@ static int launch_conv_b16(const b16_t* x, const b16_t* wp, const float* bias, b
     return check_launch("holo_conv3x3_bf16");
 }
 
+// ================================================================================================================
+// Last layer, bf16 input: ReflectionPad2d(1) -> Conv2d(64, 2, 3x3), no activation (net.py:72-73), NHWC bf16 in, NCHW fp32
+// amplitude / phase planes out.  As a VALU kernel (conv_direct.hip: 1152 FMAs, 144 LDS reads and the bf16 -> fp32 conversion of
+// every halo element per pixel) it ran at 2.1 TB/s of its input read.  Here it is 18 v_mfma_f32_16x16x32_bf16 per 16 pixels:
+//   D[pixel][n] += X[pixel][k] * W'[k][n],  n = 0..5 of 16 columns: the two output channels' fp32 weights split EXACTLY into
+//   three bf16 pieces (hi, mid, lo: 8 + 8 + 8 mantissa bits), so the products are the fp32-weight products and the result keeps
+//   the fp32-weight accuracy of the VALU kernel; columns 6..15 are zero (the matrix pipe has 16 x the VALU's rate to burn).
+// The weight fragments live in REGISTERS (18 x 4 VGPRs, built once per persistent block from the OIHW tensor); the bf16 halo
+// (18 x 18 pixels x 128 B) goes to LDS by LDS-DMA with no conversion; two blocks per CU overlap each other's load phases.
+// LDS image: pixel rows of 128 B, unit' = unit ^ (hx & 6): conflict-free ds_read_b128 for 16 consecutive pixels (scratch/swz_search.py).
+// ================================================================================================================
+struct B16L {
+    static constexpr int THREADS = 256, T = 16, HW = 18;
+    static constexpr int A_UNITS = HW * HW * 8;
+    static constexpr int A_ROUNDS = (A_UNITS + THREADS - 1) / THREADS;     // 11
+    static constexpr int A_BYTES = A_ROUNDS * THREADS * 16;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_last_b16_kernel(const b16_t* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                               int tiles_x, int tiles_y, int total_tiles) {
+    using C = B16L;
+    __shared__ __attribute__((aligned(16))) unsigned char halo[C::A_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, ku = lane >> 4;
+    // ---- weight fragments: lane (n, ku) holds W'[k = 32 kc + 8 ku + j][n] of every tap; n = 2 * piece + channel ----
+    b16x8 wf[9][2];
+    {
+        const int co = n & 1, piece = n >> 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = 0.0f;
+                    if (n < 6) {
+                        const float f = w[((size_t)co * 64 + 32 * kc + 8 * ku + j) * 9 + tap];     // OIHW (2, 64, 3, 3)
+                        const float hi = (float)(b16_t)f;
+                        const float mid = (float)(b16_t)(f - hi);
+                        const float lo = (float)(b16_t)((f - hi) - mid);
+                        v = piece == 0 ? hi : (piece == 1 ? mid : lo);
+                    }
+                    wf[tap][kc][j] = (b16_t)v;
+                }
+    }
+    const float bsel = bias[n & 1];
+    const int wave_base = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+    const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)halo;
+    // per-lane read base: pixel (x = n, row = 4 * wave) of the halo, unit ku; + tap / tile-row offsets as immediates; the swizzle
+    // follows bits 1..2 of the halo column n + dx
+    int a_lane[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) a_lane[dx] = ((4 * wave) * C::HW + n + dx) * 128 + ((ku ^ ((n + dx) & 6)) << 4);
+
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        int r = t;
+        const int tx = r % tiles_x;
+        r /= tiles_x;
+        const int ty = r % tiles_y;
+        const int img = r / tiles_y;
+        const int x0 = tx * C::T, y0 = ty * C::T;
+        const b16_t* __restrict__ xi = x + (size_t)img * H * W * 64;
+        // halo -> LDS (every lane issues A_ROUNDS loads; lanes past the image fetch a valid dummy unit into the padding)
+#pragma unroll
+        for (int rr = 0; rr < C::A_ROUNDS; ++rr) {
+            const int u = tid + rr * C::THREADS;
+            const int q = u < C::A_UNITS ? u >> 3 : 0;
+            const int hy = q / C::HW, hx = q % C::HW;
+            const int ry = reflect1(y0 - 1 + hy, H), rx = reflect1(x0 - 1 + hx, W);
+            const unsigned src = (unsigned)((ry * W + rx) * 64 + 8 * ((u & 7) ^ (hx & 6))) * 2u;
+            unsigned m0_keep;
+            const unsigned lds_u = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(rr * C::THREADS * 16 + wave_base));
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_keep)
+                         : "v"(src), "s"(xi), "s"(lds_u)
+                         : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const b16x8 a = *reinterpret_cast<const b16x8*>(halo + (a_lane[tap % 3] ^ (kc << 6)) + (mt + tap / 3) * C::HW * 128);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[tap][kc], acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();     // the halo is consumed: the next tile's loads may overwrite it
+        // D[pixel = 4 ku + i][n]: channel c = n & 1 is the sum of columns c, c + 2, c + 4 (hi, mid, lo pieces)
+        float* __restrict__ yi = y + (size_t)img * 2 * H * W;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a0 = acc[mt][i];
+                const float a2 = __shfl_down(a0, 2, 16), a4 = __shfl_down(a0, 4, 16);
+                v[i] = (a0 + a2) + a4 + bsel;
+            }
+            const int Y = y0 + 4 * wave + mt, X = x0 + 4 * ku;
+            if (n < 2 && Y < H) {
+                float* dst = yi + (size_t)n * H * W + (size_t)Y * W + X;
+                if (X + 3 < W && (W & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (X + i < W) dst[i] = v[i];
+                }
+            }
+        }
+    }
+}
+
+int conv_last_b16_try(const void* x, const float* w, const float* bias, float* y, int batch, int h, int w_px, hipStream_t stream) {
+    const int tiles_x = ceil_div(w_px, B16L::T), tiles_y = ceil_div(h, B16L::T);
+    const long tiles = (long)batch * tiles_x * tiles_y;
+    // chosen per image and for the open batch bucket only (common.h kOpenBatchBucket): images of >= 64 tiles (128 x 128) in batches
+    // >= 13; anything smaller keeps the one-tile-per-block VALU kernel
+    if (batch < kOpenBatchBucket || (long)tiles_x * tiles_y < 64 || tiles >= 2147483647L || (long)h * w_px * 64 >= (1L << 30)) return -1;
+    const long slots = (long)device_cus() * 2;
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    hipLaunchKernelGGL(conv_last_b16_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const b16_t*>(x), w, bias, y, h, w_px, tiles_x,
+                       tiles_y, (int)tiles);
+    return check_launch("holo_conv_last_bf16");
+}
+
 // Called by conv3x3_entry<bf16> (conv_mfma.hip) for the layers this kernel covers; returns -1 when it does not take the layer.
 int conv3x3_b16_try(const void* x, const void* wp, const float* bias, void* y, int batch, int h, int w, int cin, int cout, int relu,
                     int pool, int variant, hipStream_t stream) {

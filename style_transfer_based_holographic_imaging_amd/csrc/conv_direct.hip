@@ -238,6 +238,9 @@ static int conv_first_entry(const float* x, const float* w0, const float* b0, co
     return check_launch("holo_conv_first");
 }
 
+// conv_bf16.hip: the matrix-core form of the last layer for bf16 activations; -1 when it does not take the problem
+int conv_last_b16_try(const void* x, const float* w, const float* bias, float* y, int batch, int h, int w_px, hipStream_t stream);
+
 template <typename T>
 static int conv_last_entry(const T* x_nhwc, const float* w_oihw, const float* bias, float* y_nchw, int batch, int h, int w,
                            void* stream) {
@@ -247,6 +250,12 @@ static int conv_last_entry(const T* x_nhwc, const float* w_oihw, const float* bi
     const int tiles_x = ceil_div(w, kLT), tiles_y = ceil_div(h, kLT);
     const long blocks = (long)batch * tiles_x * tiles_y;
     HOLO_REQUIRE(blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "holo_conv_last: grid of %ld blocks", blocks);
+    if constexpr (__is_same(T, bf16_t)) {
+        if (conv_tile_override() != 1) {     // holo_debug_set_conv_tile(1) keeps the VALU kernel (A/B, tests)
+            const int r = conv_last_b16_try(x_nhwc, w_oihw, bias, y_nchw, batch, h, w, as_stream(stream));
+            if (r >= 0) return r;
+        }
+    }
     hipLaunchKernelGGL((conv_last_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x_nhwc, w_oihw, bias,
                        y_nchw, h, w, tiles_x, tiles_y);
     return check_launch("holo_conv_last");

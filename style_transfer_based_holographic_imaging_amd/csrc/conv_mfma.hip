@@ -816,14 +816,19 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
         // Large layers with Cin >= 128 and Cout % 128 == 0: the 512 px x 128 co blocks of conv_bf16.hip, from 1.5 blocks per CU up (measured
         // +5-9 % on the 256- and 512-channel layers, level at 128 -> 128, behind the 4-wave tile at Cin = 64: profiles/r04_bf16_layer_ab.txt)
         // (holo_debug_set_conv_tile 8 forces them, also for Cout = 64; 1 keeps the older kernel)
-        // 64 -> 64 layers on many tiles: the weights-resident persistent kernel (holo_debug_set_conv_tile 9 forces it)
+        // The v_mfma_f32_16x16x32_bf16 kernels of conv_bf16.hip (another summation grouping: chosen per image, open batch bucket only,
+        // common.h kOpenBatchBucket).  64 -> 64 layers of images >= 128 x 128: the weights-resident persistent kernel
+        // (holo_debug_set_conv_tile 9 forces it); Cin >= 128, Cout % 128 == 0 with >= 30 tiles per image: the staged 512 px x 128 co
+        // kernel (8 forces it, also for Cout = 64; measured +5-9 % on the 256- and 512-channel layers, level at 128 -> 128, behind the
+        // 4-wave tile at Cin = 64: profiles/r04_bf16_layer_ab.txt); 1 keeps the older kernel
+        const long img_tiles = (long)ceil_div(w, 16) * ceil_div(h, 32);
         if (conv_kc<T>(cin, cout, false) == KCD && cin == 64 && cout == 64 &&
-            (force == 9 || (force == 0 && (long)batch * ceil_div(w, 16) * ceil_div(h, 32) >= 512))) {
+            (force == 9 || (force == 0 && batch >= kOpenBatchBucket && img_tiles >= 32))) {
             const int r = conv3x3_b16_try(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, 3, s);
             if (r >= 0) return r;
         }
         if (conv_kc<T>(cin, cout, false) == KCD &&
-            (force == 8 || (force == 0 && cout % 128 == 0 && cin >= 128 && (long)batch * ceil_div(w, 16) * ceil_div(h, 32) * (cout / 128) >= 384))) {
+            (force == 8 || (force == 0 && batch >= kOpenBatchBucket && cout % 128 == 0 && cin >= 128 && img_tiles * (cout / 128) >= 30))) {
             const int r = conv3x3_b16_try(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, 1, s);
             if (r >= 0) return r;
         }

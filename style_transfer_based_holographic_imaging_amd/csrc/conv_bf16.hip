@@ -741,6 +741,243 @@ int conv_last_b16_try(const void* x, const float* w, const float* bias, float* y
     return check_launch("holo_conv_last_bf16");
 }
 
+// ================================================================================================================
+// First layer, bf16 output: vgg[0:4]  Conv2d(1,3,1x1) -> ReflectionPad2d(1) -> Conv2d(3,64,3x3) -> ReLU (net.py:77-80), one fp32
+// plane in, NHWC bf16 out.  On the fp32 MFMA (conv_direct.hip) the layer's 14 k-steps cost 3.6 k matrix-pipe cycles per 256
+// pixels, as much as its 32 KB output write; the two did not overlap (0.84 ms at 64 x 512^2 for 0.43 ms of writes).  Here K = 27
+// (padded to 32) is ONE step of v_mfma_f32_16x16x32_bf16 with both operands split into two bf16 pieces (a = hi + lo: 16 mantissa
+// bits): hi*hi + hi*lo + lo*hi, 48 MFMAs of 16 cycles per wave and 256 pixels.  The products carry 2^-16, far below the bf16
+// rounding of the output (2^-9): the result is the fp32 kernel's up to rare one-ulp differences at rounding boundaries.
+//   D[co][pixel] = sum_k W1[co][k] * A[pixel][k],   A[pixel][9c + tap] = w0[c] * in(pixel + tap) + b0[c]   (vgg[0] on the fly)
+// Same wave geometry and epilogue as the 3x3 kernels (4 rows x 16 columns per wave, b16_store_tile).
+// ================================================================================================================
+__global__ __launch_bounds__(256, 3) void conv_first_b16_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+                                                                const float* __restrict__ b0, const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, b16_t* __restrict__ y, int H, int W,
+                                                                int tiles_x, int tiles_y, int total_tiles) {
+    constexpr int HW = 18;
+    __shared__ float halo[HW * HW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, ku = lane >> 4;
+    const int lpx = (p & 1) | ((p >> 2) << 1);
+    const int lpy = wave * 4 + ((p >> 1) & 1);
+    // weights: lane (co = 16 nt + p, ku) holds W1[co][k = 8 ku + j] split into hi / lo
+    b16x8 whi[4], wlo[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * ku + j;
+            const float f = k < 27 ? w1[(16 * nt + p) * 27 + k] : 0.0f;          // OIHW (64,3,3,3) = [co][27]
+            const b16_t hi = (b16_t)f;
+            whi[nt][j] = hi;
+            wlo[nt][j] = (b16_t)(f - (float)hi);
+        }
+    // this lane's 8 columns of A: halo offset of the tap and the 1x1 pre-conv's scale / offset of the channel
+    int koff[8];
+    float kw[8], kb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * ku + j;
+        const int kk = k < 27 ? k : 0;
+        const int c = kk / 9, tap = kk % 9;
+        koff[j] = (tap / 3) * HW + tap % 3;
+        kw[j] = k < 27 ? w0[c] : 0.0f;          // the padded columns multiply zero weights: make them exact zeros all the same
+        kb[j] = k < 27 ? b0[c] : 0.0f;
+    }
+    f32x4 biasq[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(b1 + nt * 16 + 4 * ku);
+        biasq[nt] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        B16Tile cur = b16_decode(t, 1, tiles_x, tiles_y, 16, 64);
+        const float* __restrict__ xi = x + (size_t)cur.img * H * W;
+        __syncthreads();      // the previous tile's halo is consumed
+        for (int i = tid; i < HW * HW; i += 256) {
+            const int hy = i / HW, hx = i % HW;
+            halo[i] = xi[reflect1(cur.y0 - 1 + hy, H) * W + reflect1(cur.x0 - 1 + hx, W)];
+        }
+        __syncthreads();
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int hbase = (lpy + (mt >> 1) * 2) * HW + lpx + (mt & 1) * 8;
+            b16x8 ahi, alo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = halo[hbase + koff[j]] * kw[j] + kb[j];
+                const b16_t hi = (b16_t)a;
+                ahi[j] = hi;
+                alo[j] = (b16_t)(a - (float)hi);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[nt], ahi, biasq[nt], 0, 0, 0);   // small terms first
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[nt], alo, c, 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[nt], ahi, c, 0, 0, 0);
+            }
+        }
+        b16_store_tile<4>(acc, cur, y, H, W, 64, 1, 0, p, ku, lpx, lpy, 0);
+    }
+}
+
+int conv_first_b16_try(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* y, int batch, int h,
+                       int w_px, hipStream_t stream) {
+    const int tiles_x = ceil_div(w_px, 16), tiles_y = ceil_div(h, 16);
+    const long tiles = (long)batch * tiles_x * tiles_y;
+    // per image, open batch bucket only (common.h kOpenBatchBucket): images of >= 64 tiles (128 x 128)
+    if (batch < kOpenBatchBucket || (long)tiles_x * tiles_y < 64 || tiles >= 2147483647L) return -1;
+    const long slots = (long)device_cus() * 3;
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    hipLaunchKernelGGL(conv_first_b16_kernel, dim3(grid), dim3(256), 0, stream, x, w0, b0, w1, b1, static_cast<b16_t*>(y), h, w_px, tiles_x,
+                       tiles_y, (int)tiles);
+    return check_launch("holo_conv_first_bf16");
+}
+
+// ================================================================================================================
+// ConvTranspose2d(64, 64, k=2, s=2) + ReLU in bf16 (net.py:64, the decoder's last up-sampling: half of the transposed
+// convolutions' time): a one-tap GEMM, out[2Y+dy][2X+dx][co] = sum_ci in[Y][X][ci] * W[ci][co][dy][dx], that moves 128 B in and
+// 512 B out per input pixel for 32 kFLOP — pure streaming.  The generic kernel (conv_mfma.hip) gave a block two K stages between
+// its prologue and epilogue and reached 3.2 TB/s.  Here the packed weights [2 chunks][4 * 64 columns][32] (32 KB) are staged once
+// per persistent block and a tile is 256 input pixels (32 KB by LDS-DMA, no halo): each wave keeps its 64 pixels' fragments in
+// registers and runs the four quadrants (dy, dx) as 4 x 32 MFMAs, storing 16-byte runs of the (2H x 2W) NHWC output after each.
+// ================================================================================================================
+struct B16T {
+    static constexpr int THREADS = 256;
+    static constexpr int W_BYTES = 2 * 256 * 64;           // [chunk][n = q * 64 + co][32 ch]
+    static constexpr int A_BYTES = 2 * 256 * 64;           // [chunk][256 pixels][32 ch]
+    static constexpr int LDS_BYTES = W_BYTES + A_BYTES;
+};
+
+__global__ __launch_bounds__(256, 2) void convt2x2_b16_c64_kernel(const b16_t* __restrict__ x, const b16_t* __restrict__ wp,
+                                                                   const float* __restrict__ bias, b16_t* __restrict__ y, int H, int W,
+                                                                   int tiles_x, int tiles_y, int total_tiles, int relu) {
+    using C = B16T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_w = smem;
+    unsigned char* lds_a = smem + C::W_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, ku = lane >> 4;
+    const int lpx = (p & 1) | ((p >> 2) << 1);
+    const int lpy = wave * 4 + ((p >> 1) & 1);
+    const int wave_base = __builtin_amdgcn_readfirstlane((tid & ~63) * 16);
+    const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
+#define B16T_GLDS(sbase_, voff_, ldst_)                                                                     \
+    {                                                                                                      \
+        unsigned m0_keep;                                                                                  \
+        const unsigned lds_u = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(ldst_));               \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t" \
+                     "s_mov_b32 m0, %0"                                                                     \
+                     : "=&s"(m0_keep)                                                                      \
+                     : "v"(voff_), "s"(sbase_), "s"(lds_u)                                                 \
+                     : "memory");                                                                          \
+    }
+    // weights once: 2 chunks x 256 rows x 4 units = 2048 units; row swizzle as in the 3x3 kernels
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int u = tid + r * C::THREADS;
+        const int row = u >> 2, c = (u & 3) ^ b16_swz_b(row & 255);
+        const int src = (row * kB16KC + 8 * c) * 2;
+        B16T_GLDS(wp, src, r * C::THREADS * 16 + wave_base)
+    }
+    f32x4 biasq[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + nt * 16 + 4 * ku);
+        biasq[nt] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+    const int b_off0 = p * 64 + ((ku ^ b16_swz_b(p)) << 4);
+    // pixel fragments: tile pixel q = ty * 16 + tx at LDS row q (64 B per chunk); the row pitch is 16 pixels = 4 bank rows exactly,
+    // so the unit swizzle takes the tile row's parity besides bit 1 of the column: conflict-free ds_read_b128 (scratch/swz_search.py)
+    auto a_swz = [](int tx, int ty) { return (((tx >> 1) ^ ty) & 1) << 1; };
+    const float fl = relu ? 0.0f : -__builtin_inff();
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const B16Tile cur = b16_decode(t, 1, tiles_x, tiles_y, 16, 64);
+        const b16_t* __restrict__ xi = x + (size_t)cur.img * H * W * 64;
+        __syncthreads();      // the previous tile's pixels are consumed
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int u = tid + r * C::THREADS;                  // chunk = u >> 10, pixel = (u >> 2) & 255, unit = u & 3
+            const int chunk = u >> 10, q = (u >> 2) & 255;
+            const int ty = q >> 4, tx = q & 15;
+            const int Y = min(cur.y0 + ty, H - 1), X = min(cur.x0 + tx, W - 1);       // overhang: clamped (masked at the store)
+            const int c = (u & 3) ^ a_swz(tx, ty);
+            const unsigned src = (unsigned)((Y * W + X) * 64 + chunk * 32 + 8 * c) * 2u;
+            B16T_GLDS(xi, src, C::W_BYTES + r * C::THREADS * 16 + wave_base)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        b16x8 af[2][4];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int tx = lpx + (mt & 1) * 8, ty = lpy + (mt >> 1) * 2;
+                af[kc][mt] = *reinterpret_cast<const b16x8*>(lds_a + kc * (256 * 64) + (ty * 16 + tx) * 64 + ((ku ^ a_swz(tx, ty)) << 4));
+            }
+        b16_t* __restrict__ yimg = y + (size_t)cur.img * (2 * H) * (2 * W) * 64;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const b16x8 b0 = *reinterpret_cast<const b16x8*>(lds_w + (qd * 64 + nt * 16) * 64 + b_off0);
+                const b16x8 b1 = *reinterpret_cast<const b16x8*>(lds_w + 256 * 64 + (qd * 64 + nt * 16) * 64 + b_off0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[0][mt], biasq[nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, af[1][mt], c, 0, 0, 0);
+                }
+            }
+            // output pixel (2Y + dy, 2X + dx), channels nt*16 + 4*ku ..: pairs of channel tiles joined into 16-byte runs
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int X = cur.x0 + lpx + (mt & 1) * 8, Y = cur.y0 + lpy + (mt >> 1) * 2;
+                const bool inside = X < W && Y < H;
+                const size_t pix = (size_t)(2 * Y + (qd >> 1)) * (2 * W) + (2 * X + (qd & 1));
+#pragma unroll
+                for (int nt = 0; nt < 4; nt += 2) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+                        const f32x4 a = acc[mt][nt + h2];
+                        const b16x2 lo = {(b16_t)fmaxf(a[0], fl), (b16_t)fmaxf(a[1], fl)}, hi = {(b16_t)fmaxf(a[2], fl), (b16_t)fmaxf(a[3], fl)};
+                        pk[h2][0] = __builtin_bit_cast(unsigned, lo);
+                        pk[h2][1] = __builtin_bit_cast(unsigned, hi);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[1][0], pk[0][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[1][1], pk[0][1], false, false);
+                    const int ch = nt * 16 + ((ku & 1) ? 0 : 16) + (ku >> 1) * 8;
+                    if (inside) *reinterpret_cast<uint4*>(yimg + pix * 64 + ch) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        }
+    }
+#undef B16T_GLDS
+}
+
+int convt2x2_b16_try(const void* x, const void* wp, const float* bias, void* y, int batch, int h, int w, int cin, int cout, int relu,
+                     hipStream_t stream) {
+    if (cin != 64 || cout != 64) return -1;
+    const int tiles_x = ceil_div(w, 16), tiles_y = ceil_div(h, 16);
+    const long tiles = (long)batch * tiles_x * tiles_y;
+    // per image, open batch bucket only (common.h kOpenBatchBucket): input images of >= 16 tiles (64 x 64)
+    if (batch < kOpenBatchBucket || (long)tiles_x * tiles_y < 16 || tiles >= 2147483647L) return -1;
+    static DeviceOnce attr_once;
+    attr_once.run([] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convt2x2_b16_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  B16T::LDS_BYTES);
+    });
+    const long slots = (long)device_cus() * 2;
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    hipLaunchKernelGGL(convt2x2_b16_c64_kernel, dim3(grid), dim3(256), B16T::LDS_BYTES, stream, static_cast<const b16_t*>(x),
+                       static_cast<const b16_t*>(wp), bias, static_cast<b16_t*>(y), h, w, tiles_x, tiles_y, (int)tiles, relu);
+    return check_launch("holo_convt2x2_bf16");
+}
+
 // Called by conv3x3_entry<bf16> (conv_mfma.hip) for the layers this kernel covers; returns -1 when it does not take the layer.
 int conv3x3_b16_try(const void* x, const void* wp, const float* bias, void* y, int batch, int h, int w, int cin, int cout, int relu,
                     int pool, int variant, hipStream_t stream) {

@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const T* __restrict__ x,
     }
 }
 
+// conv_bf16.hip: the first layer as one split-bf16 MFMA step for bf16 activations; -1 when it does not take the problem
+int conv_first_b16_try(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* y, int batch, int h,
+                       int w_px, hipStream_t stream);
+
 template <typename T>
 static int conv_first_entry(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, T* y_nhwc,
                             int batch, int h, int w, void* stream) {
@@ -233,6 +237,12 @@ static int conv_first_entry(const float* x, const float* w0, const float* b0, co
     const int tiles_x = ceil_div(w, kFT), tiles_y = ceil_div(h, kFT);
     const long blocks = (long)batch * tiles_x * tiles_y;
     HOLO_REQUIRE(blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "holo_conv_first: grid of %ld blocks", blocks);
+    if constexpr (__is_same(T, bf16_t)) {
+        if (conv_tile_override() != 1) {     // holo_debug_set_conv_tile(1) keeps the fp32-MFMA kernel (A/B, tests)
+            const int r = conv_first_b16_try(x, w0, b0, w1, b1, y_nhwc, batch, h, w, as_stream(stream));
+            if (r >= 0) return r;
+        }
+    }
     hipLaunchKernelGGL((conv_first_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, w0, b0, w1, b1,
                        y_nhwc, h, w, tiles_x, tiles_y);
     return check_launch("holo_conv_first");

@@ -870,6 +870,10 @@ static int conv3x3_entry(const T* x_nhwc, const T* w_packed, const float* bias, 
     return launch_conv<4, 1, false, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, pool, s);
 }
 
+// conv_bf16.hip: the weights-resident streaming kernel for the 64 -> 64 transposed convolution; -1 when it does not take the layer
+int convt2x2_b16_try(const void* x, const void* wp, const float* bias, void* y, int batch, int h, int w, int cin, int cout, int relu,
+                     hipStream_t stream);
+
 template <typename T>
 static int convt2x2_entry(const T* x_nhwc, const T* w_packed, const float* bias, T* y_nhwc, int batch, int h, int w,
                           int cin, int cout, int relu, void* stream) {
@@ -882,6 +886,12 @@ static int convt2x2_entry(const T* x_nhwc, const T* w_packed, const float* bias,
     // a 128-wide N tile would straddle two (dy,dx) quadrants when Cout % 128 != 0: use the 64-wide tile then
     hipStream_t s = as_stream(stream);
     constexpr int KCD = (sizeof(T) == 2 || __is_same(T, split16)) ? 32 : 16;
+    if constexpr (sizeof(T) == 2) {
+        if (conv_tile_override() != 1) {     // holo_debug_set_conv_tile(1) keeps the generic kernel (A/B, tests)
+            const int r = convt2x2_b16_try(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, s);
+            if (r >= 0) return r;
+        }
+    }
     if constexpr (__is_same(T, split16))   // two accumulator sets: the 64 px x 32 co wave tile keeps two waves per SIMD
         return launch_conv<2, 2, true, KCD, T, 2, 1>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);
     if (cout % 128 == 0) return launch_conv<2, 2, true, KCD, T>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout, relu, 0, s);

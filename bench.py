@@ -83,12 +83,12 @@ def cpu_baseline(size, sds, style, sample, seed):
                       f"torch {torch.__version__} CPU"}
 
 
-PMC_PROFILE = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
+PMC_PROFILE = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
 
 
 def pmc_traffic(batch, size, dtype, distances, single_rank_step=True):
     """HBM bytes (conv: per launch; propagator: per call) from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    over this same command (scripts/collect_pmc.py -> profiles/r03_pmc_traffic.json; FETCH_SIZE doubled per
+    over this same command (scripts/collect_pmc.py -> profiles/r04_pmc_traffic.json; FETCH_SIZE doubled per
     MI355X_MICROARCH.md §HBM).  Counters cannot be read from inside the process, so the numbers are only reported for the
     workload AND the library build they were collected on (the profile stores the library's source hash): anything else
     gives null rather than a stale figure."""
@@ -373,7 +373,9 @@ def main():
                                    "frac": round(ach / peak, 4), "traffic": traffic_conv, "traffic_source": traffic_src,
                                    "algorithmic_bytes_per_launch": round(sum(r["bytes"] for r in conv) / calls),
                                    "kernel": "conv_wino_f32_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, all large 3x3 layers)" if wino
-                                   else f"conv_mfma_kernel<{args.dtype}> (3x3 + transposed, all layers)",
+                                   else ("bf16 3x3 + transposed convolutions, all layers: conv3x3_b16_kernel / conv3x3_b16_wres_kernel / "
+                                         "convt2x2_b16_c64_kernel (v_mfma_f32_16x16x32_bf16) and conv_mfma_kernel<bf16> (32x32x16) for the rest"
+                                         if args.dtype == "bf16" else f"conv_mfma_kernel<{args.dtype}> (3x3 + transposed, all layers)"),
                                    "launches_per_step": calls // args.steps, "avg_launch_ms": round(ms / calls, 4),
                                    "gflop_per_launch": round(fl * (16.0 / 36.0 if wino else 1.0) / calls / 1e9, 3)}
                 if wino:

@@ -10,7 +10,7 @@ and only the LAST step's dispatches are summed (the first ones include weight pa
 Writes profiles/<name>.json with the hash of the library the numbers belong to; bench.py reports
 `roofline.traffic` from that file only while the hash matches the loaded library.
 
-    python scripts/collect_pmc.py --out profiles/r03_pmc_traffic.json [-- bench args]
+    python scripts/collect_pmc.py --out profiles/r04_pmc_traffic.json [-- bench args]
 """
 import argparse
 import csv
@@ -25,8 +25,10 @@ sys.path.insert(0, REPO)
 
 # kernel-name prefixes -> keys of the output ("wino": the Winograd 3x3 kernel, the dominant one; "conv": the implicit-GEMM
 # kernel, which still runs the transposed convolutions and the small 3x3 layers)
-KEYS = (("conv_wino_f32_kernel", "wino"), ("conv_mfma_kernel", "conv"), ("asm_rows_fwd", "asm_rows_fwd"), ("asm_cols", "asm_cols"),
-        ("asm_rows_inv", "asm_rows_inv"))
+KEYS = (("conv_wino_f32_kernel", "wino"), ("conv_mfma_kernel", "conv"), ("conv3x3_b16_wres_kernel", "b16_wres"),
+        ("conv3x3_b16_kernel", "b16_staged"), ("convt2x2_b16_c64_kernel", "b16_convt"), ("conv_first_b16_kernel", "b16_first"),
+        ("conv_last_b16_kernel", "b16_last"), ("asm_rows_fwd", "asm_rows_fwd"), ("asm_cols", "asm_cols"), ("asm_rows_inv", "asm_rows_inv"))
+SQ_KEYS = ("wino", "conv", "b16_wres", "b16_staged", "b16_convt", "b16_first", "b16_last")
 ASM = ("asm_rows_fwd", "asm_cols", "asm_rows_inv")
 
 
@@ -55,12 +57,12 @@ def one_pass(counter, outdir, bench_args):
 
 def last_step(rows):
     """dispatches of the last bench step: from the last conv_first launch on (each step starts with it)"""
-    firsts = sorted({r[0] for r in rows if "conv_first_kernel" in r[1]})
+    firsts = sorted({r[0] for r in rows if "conv_first" in r[1]})
     if len(firsts) > 2:
         lo = firsts[2]
         hi = firsts[3] if len(firsts) > 3 else 1 << 60
         return [r for r in rows if lo <= r[0] < hi]
-    starts = [i for i, r in enumerate(rows) if "conv_first_kernel" in r[1]]
+    starts = [i for i, r in enumerate(rows) if "conv_first" in r[1]]
     # bench: 1 warm-up + 2 timed steps + (unwrap probe step, f32s steps) afterwards; take the 3rd start (2nd timed step)
     i0 = starts[2] if len(starts) > 2 else starts[-1]
     i1 = starts[3] if len(starts) > 3 else len(rows)
@@ -69,8 +71,8 @@ def last_step(rows):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(REPO, "profiles", "r03_pmc_traffic.json"))
-    ap.add_argument("--scratch", default=os.path.join(REPO, "gpurun_out", "pmc_r03"))
+    ap.add_argument("--out", default=os.path.join(REPO, "profiles", "r04_pmc_traffic.json"))
+    ap.add_argument("--scratch", default=os.path.join(REPO, "gpurun_out", "pmc_r04"))
     ap.add_argument("bench_args", nargs="*")
     args = ap.parse_args()
     from style_transfer_based_holographic_imaging_amd import build
@@ -99,14 +101,15 @@ def main():
     # SQ / GRBM view of the dominant kernels (one pass: 8 SQ slots + GRBM): matrix-pipe utilisation, clock, wait fractions.
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the chip's 1024 SIMDs; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count
     # quad-cycles per wave; GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, cycle constants / DVFS notes).
-    sq = "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+    mops = "SQ_INSTS_VALU_MFMA_MOPS_BF16" if "bf16" in args.bench_args else "SQ_INSTS_VALU_MFMA_MOPS_F32"
+    sq = f"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES {mops} SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
     try:
         rows = last_step(one_pass(sq, os.path.join(args.scratch, "sq"), args.bench_args))
         agg = {}
         for did, name, cn, val, t0, t1 in rows:
             short = name.split("(")[0]
             key = next((k for pre, k in KEYS if pre in short), None)
-            if key not in ("wino", "conv"):
+            if key not in SQ_KEYS:
                 continue
             a = agg.setdefault(key, {"ns": {}, "c": {}})
             a["ns"][did] = t1 - t0

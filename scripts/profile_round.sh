@@ -2,7 +2,7 @@
 # Round profile on the GPU box: rocprofv3 kernel stats of the default bench, the other BASELINE configurations, the
 # bundled-size case per convolution algorithm, PMC traffic (scripts/collect_pmc.py), the propagator alone.
 # Outputs under gpurun_out/ (copy what is judged into profiles/).  PART=1 | 2 | all (a gpurun call is limited to 20 min).
-R=${1:-r03}
+R=${1:-r04}
 PART=${2:-all}
 O=/root/repo/gpurun_out
 if [ $PART = 1 ] || [ $PART = all ]; then
@@ -14,6 +14,16 @@ python scripts/collect_pmc.py --out $O/${R}_pmc_traffic.json > $O/${R}_pmc.log 2
 cp $O/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json      # bench.py reads the traffic figures of THIS library from profiles/
 python bench.py > $O/${R}_bench_default.json 2> $O/${R}_bench_default.err
 python scripts/per_layer.py > $O/${R}_layers.txt 2>&1
+fi
+if [ $PART = 3 ] || [ $PART = all ]; then
+cd /root/repo
+# BASELINE configs[2]: counters of the bf16 convolution kernels (FETCH_SIZE / WRITE_SIZE / SQ in separate passes) and per-layer times
+python scripts/collect_pmc.py --out $O/${R}_pmc_config3_bf16_conv.json --scratch $O/pmc_${R}_c3 -- --dtype bf16 --batch 256 --size 512 > $O/${R}_pmc_c3.log 2>&1
+python scripts/per_layer.py --batch 64 --size 512 --dtype bf16 --reps 3 > $O/${R}_layers_bf16_b64_s512.txt 2>&1
+python scripts/bf16_layer_bench.py --tiles 1,8,9 > $O/${R}_bf16_layer_ab.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/${R}_prof_c3 -o bench --output-format csv -- python3 /root/repo/bench.py --dtype bf16 --batch 256 --size 512 --steps 3 --warmup 1 --cpu-sample 0 > $O/${R}_prof_c3.json 2> $O/${R}_prof_c3.err
+cd /root/repo
 fi
 if [ $PART = 2 ] || [ $PART = all ]; then
 cd /root/repo
@@ -33,7 +43,7 @@ python scripts/per_layer.py --batch 5 --size 128 --reps 20 > $O/${R}_layers_b5.t
 fi
 R_=$R python - <<'PY'
 import json,glob,os
-for f in sorted(glob.glob('/root/repo/gpurun_out/REPL_bench_*.json'.replace('REPL', os.environ.get('R_','r03')))):
+for f in sorted(glob.glob('/root/repo/gpurun_out/REPL_bench_*.json'.replace('REPL', os.environ.get('R_','r04')))):
     try:
         d=json.load(open(f)); r=d.get('roofline',{}); p=d.get('roofline_propagator',{})
         print(os.path.basename(f), d['value'], d['ms_per_step'], r.get('achieved'), r.get('frac'), p.get('achieved'), p.get('avg_call_ms'))

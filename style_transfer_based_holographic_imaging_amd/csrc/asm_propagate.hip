@@ -767,7 +767,7 @@ struct ColTCfg {
 template <int P, bool PAD, bool SWEEP>
 __global__ __launch_bounds__(ColTCfg<P>::THREADS, SWEEP ? (ColTCfg<P>::WAVES_PER_SIMD > 4 ? 4 : ColTCfg<P>::WAVES_PER_SIMD) : ColTCfg<P>::WAVES_PER_SIMD) void asm_cols_t_kernel(
     const v2f* __restrict__ tbuf, v2f* __restrict__ ubuf, const double* __restrict__ phase_const,
-    int n_dist, double inv_ppx, double lam2, double lamb, int ablate, const v2f* __restrict__ htab) {
+    int n_dist, double inv_ppx, double lam2, double lamb, int ablate, const v2f* __restrict__ htab, int n_tiles) {
     using C = ColTCfg<P>;
     constexpr int S = PAD ? P / 2 : P;
     constexpr int CW = C::CW, G = C::G, E = C::E, PITCH = C::PITCH, THREADS = C::THREADS;
@@ -779,21 +779,21 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, SWEEP ? (ColTCfg<P>::WAVES_PER
     v2f* twf = reinterpret_cast<v2f*>(smem_raw);
     v2f* twi = SYM ? twf : twf + tw_entries_fwd<P>();
     v2f* cols = twf + C::TWN;
-    __shared__ int s_uid;
 
     const int tid = threadIdx.x;
-    // one-distance form: blockIdx.y = output field (= field * n_dist + dist); SWEEP: blockIdx.y = field, distances looped below
-    const int f = SWEEP ? (int)blockIdx.y : (int)blockIdx.y / n_dist;
     const int col = tid / G, t = tid % G;
-    const int kx = blockIdx.x * CW + col;
     v2f* my = cols + col * PITCH;
     fft_fill_twiddles<P, -1>(twf, tid, THREADS);
     if (!SYM) fft_fill_twiddles<P, +1>(twi, tid, THREADS);
-    if (!SWEEP && tid < 64) {   // THREADS >= 64 for every P of this path except the smallest, which skips the table
-        const int u = (THREADS >= 64 && htab != nullptr) ? htab_uid_wave(phase_const, (int)blockIdx.y, tid) : -1;
-        if (tid == 0) s_uid = u;
-    }
-
+    __syncthreads();  // twiddle tables: the only block barrier
+    // PERSISTENT over tiles (round 4): tile = (output field | field of a sweep, column group).  A block fills its twiddle tables
+    // once (two sincospif per thread: ~15 % of a one-tile block's vector instructions) and walks tiles with the grid's stride; every
+    // wave is on its own after the barrier above (wave-local exchanges, per-wave table slot).
+    constexpr int NG = P / CW;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int fy = tile / NG;           // one-distance form: output field (= field * n_dist + dist); SWEEP: field
+    const int f = SWEEP ? fy : fy / n_dist;
+    const int kx = (tile % NG) * CW + col;
     // the column's S values are contiguous; rows above/below the field are copies of its first/last row spectrum
     const v2f* src = tbuf + ((long)f * P + kx) * S;
     v2f v[E];
@@ -816,7 +816,6 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, SWEEP ? (ColTCfg<P>::WAVES_PER
             }
         }
     }
-    __syncthreads();  // twiddle tables: the only block barrier
     if (!(ablate & 2)) fft_run<P, G, -1>(v, my, twf, t);   // spectrum in registers at ky = fft_elem_index<P,G,RL>(t,e)
 
     v2f spec[SWEEP ? E : 1];
@@ -826,19 +825,14 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, SWEEP ? (ColTCfg<P>::WAVES_PER
     }
     const int d_count = SWEEP ? n_dist : 1;
     for (int d = 0; d < d_count; ++d) {
-        const int fo = SWEEP ? f * n_dist + d : (int)blockIdx.y;
-        int uid;
-        if constexpr (SWEEP) {
-            // every wave finds the slot itself (a wave is 64 lanes here: THREADS >= 64 wherever a table exists)
-            uid = (THREADS >= 64 && htab != nullptr) ? htab_uid_wave(phase_const, fo, tid & 63) : -1;
-            uid = __builtin_amdgcn_readfirstlane(uid);
-            if (d > 0) {
-                fft_sync<G>();    // the inverse transform of the previous distance is done with the column's LDS region
+        const int fo = SWEEP ? f * n_dist + d : fy;
+        // every wave finds the table slot itself (a wave is 64 lanes here: THREADS >= 64 wherever a table exists)
+        int uid = (THREADS >= 64 && htab != nullptr) ? htab_uid_wave(phase_const, fo, tid & 63) : -1;
+        uid = __builtin_amdgcn_readfirstlane(uid);
+        if (SWEEP && d > 0) {
+            fft_sync<G>();    // the inverse transform of the previous distance is done with the column's LDS region
 #pragma unroll
-                for (int e = 0; e < E; ++e) v[e] = spec[e];
-            }
-        } else {
-            uid = s_uid;   // written before the twiddle barrier above
+            for (int e = 0; e < E; ++e) v[e] = spec[e];
         }
         if (uid >= 0) {
             // transfer function from this distance's table: the column's |ky| values are contiguous
@@ -880,6 +874,8 @@ __global__ __launch_bounds__(ColTCfg<P>::THREADS, SWEEP ? (ColTCfg<P>::WAVES_PER
             const int i = fft_elem_index<P, G, R1>(t, e);
             dst[PAD ? i - S / 2 : i] = v[e];
         }
+    }
+    fft_sync<G>();   // this column's LDS region is reused by the next tile's transforms
     }
 }
 
@@ -1136,14 +1132,25 @@ static int launch_asm_t(const AsmArgs& a) {
     if (a.in_mode == HOLO_ASM_IN_COMPLEX) HOLO_LAUNCH_FWD(HOLO_ASM_IN_COMPLEX);
     else HOLO_LAUNCH_FWD(HOLO_ASM_IN_AMP_PHASE);
 #undef HOLO_LAUNCH_FWD
-    if (a.n_dist > 1)    // a sweep: one block per (field, column group), the distances looped inside on the shared spectrum
-        hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD, true>), dim3(P / C::CW, a.n_fields), dim3(C::THREADS), C::LDS, a.stream,
+    // persistent column blocks: as many as are resident at once (LDS, the register-limited waves per SIMD of the variant)
+    auto col_grid = [&](long tiles, int waves_cap) {
+        const int wps = C::WAVES_PER_SIMD < waves_cap ? C::WAVES_PER_SIMD : waves_cap;
+        long per_cu = (long)wps * 256 / C::THREADS;
+        if (per_cu > C::BPC) per_cu = C::BPC;
+        if (per_cu < 1) per_cu = 1;
+        const long slots = (long)device_cus() * per_cu;
+        return (unsigned)(tiles < slots ? tiles : slots);
+    };
+    if (a.n_dist > 1)    // a sweep: tiles are (field, column group), the distances looped inside on the shared spectrum
+        hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD, true>), dim3(col_grid((long)(P / C::CW) * a.n_fields, 4)), dim3(C::THREADS), C::LDS, a.stream,
                            reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
-                           1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr);
+                           1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr,
+                           (int)((long)(P / C::CW) * a.n_fields));
     else
-        hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD, false>), dim3(P / C::CW, n_out), dim3(C::THREADS), C::LDS, a.stream,
+        hipLaunchKernelGGL((asm_cols_t_kernel<P, PAD, false>), dim3(col_grid((long)(P / C::CW) * n_out, 8)), dim3(C::THREADS), C::LDS, a.stream,
                            reinterpret_cast<const v2f*>(a.tbuf), reinterpret_cast<v2f*>(a.ubuf), a.phase_const, a.n_dist,
-                           1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr);
+                           1.0 / a.ppx, a.lam2, a.lamb, a.ablate, tables ? reinterpret_cast<const v2f*>(a.htab) : nullptr,
+                           (int)((long)(P / C::CW) * n_out));
     const float scale = 1.0f / ((float)P * (float)P);  // ifft2 "backward" normalisation; exact (power of two)
     const long tiles_out = blocks_in * a.n_dist;
     const long inv_slots = (long)device_cus() * R::bpc(tw_entries_inv<P>());

@@ -43,9 +43,11 @@ const char* holo_target_arch(void);
  * -DHOLO_SOURCE_HASH); the Python binding compares it with the hash of the sources next to it on every load, on
  * every rank, and refuses a stale library */
 const char* holo_source_hash(void);
-/* Test / A-B hook, not part of the reference's surface: force a tile variant of holo_conv3x3_* (0 = automatic, the
- * shipped behaviour; 1 = standard tile, 2 = small tile, 3 = tall bf16 wave tile).  All variants give bit-identical
- * results (tests/test_hip_bf16.py).  Process-wide. */
+/* Test / A-B hook, not part of the reference's surface: force a kernel variant of the convolutions (0 = automatic, the
+ * shipped behaviour; 1 = the round-1 kernels with the standard tile, 2 = small tile, 3 = tall bf16 wave tile, 4..7 = 8-wave
+ * tiles of the bf16 kernel: all bit-identical to each other (tests/test_hip_bf16.py); 8 = the staged 16x16x32 bf16 kernel,
+ * 9 = the weights-resident 64 -> 64 bf16 kernel (csrc/conv_bf16.hip): another summation grouping, within bf16 rounding of the
+ * others).  Process-wide. */
 int holo_debug_set_conv_tile(int tile);
 
 /* ------------------------------------------------------------------------------------------
@@ -224,7 +226,11 @@ int holo_unwrap2d_f32(const float* phase, long in_stride, float* out, long out_s
 /* ------------------------------------------------------------------------------------------
  * bf16 variants (BASELINE config 3: "bf16 convs / fp32 FFT").  Same layouts and semantics as the _f32 entry
  * points; activations and packed weights are bf16 (uint16_t storage), bias, statistics, accumulation
- * (v_mfma_f32_32x32x16_bf16) and the last layer's amplitude/phase planes stay fp32.  Cin % 32 == 0.
+ * (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16) and the last layer's amplitude/phase planes stay fp32.
+ * Cin % 32 == 0.  For batches of 13 holograms or more (the open-ended batch bucket) and images large enough to fill the
+ * chip, the conv entry points take the 16x16x32 kernels of csrc/conv_bf16.hip — chosen from per-image quantities, so that
+ * every batch >= 13 gives a hologram the same bits; they differ from the 32x32x16 kernels by the rounding of partial
+ * sums (rare one-ulp differences of the bf16 outputs).  holo_conv_last_bf16 keeps the fp32 weights exactly in both forms.
  * ---------------------------------------------------------------------------------------- */
 int holo_pack_conv3x3_weight_bf16(const float* w_oihw, uint16_t* w_packed, int cout, int cin, void* stream);
 int holo_pack_convt2x2_weight_bf16(const float* w_iohw, uint16_t* w_packed, int cin, int cout, void* stream);

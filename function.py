@@ -4,6 +4,8 @@
 keep their signatures; inputs are logical NCHW tensors on a ROCm device.  ``coral`` and friends are
 imported-but-unused in the reference and are not provided.
 """
+import torch
+
 from style_transfer_based_holographic_imaging_amd import ops
 
 
@@ -11,7 +13,12 @@ def calc_mean_std(feat, eps=1e-5):
     size = feat.size()
     assert (len(size) == 4)
     n, c = size[:2]
-    mean, std = ops.channel_mean_std(ops.to_nhwc(feat), eps)
+    x = ops.to_nhwc(feat)
+    if torch.is_grad_enabled() and x.requires_grad:      # training graph (net.py:191-197): differentiable statistics
+        from style_transfer_based_holographic_imaging_amd import autograd as _ag
+        mean, std = _ag.MeanStd.apply(x, eps)
+    else:
+        mean, std = ops.channel_mean_std(x, eps)
     return mean.view(n, c, 1, 1), std.view(n, c, 1, 1)
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 4
+#define HOLO_ABI_VERSION 5
 
 /* error codes */
 #define HOLO_OK 0
@@ -255,6 +255,55 @@ int holo_cast_bf16_to_f32(const uint16_t* x, float* y, long n, void* stream);
  * ---------------------------------------------------------------------------------------- */
 int holo_nhwc_to_nchw_f32(const float* x, float* y, int batch, int hw, int c, void* stream);
 int holo_nchw_to_nhwc_f32(const float* x, float* y, int batch, int hw, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward pass of the training objective (ABI 5; Net.forward, net.py:199-226 with the losses of net.py:186-197: the
+ * reference differentiates it with torch.autograd over aten ops).  fp32, NHWC, csrc/backward.hip.  The data gradient
+ * of ReflectionPad2d(1) + Conv2d(3x3) (net.py:34-71, 78-107) is  holo_relu_pool_bwd_pad_f32 (border 2)  ->  the
+ * FORWARD convolution (holo_conv3x3_f32 / holo_conv3x3_wino_f32) with the flipped, transposed weights  ->
+ * holo_fold_reflect_f32; its weight gradient is holo_pix_gemm_f32 (taps = 9), its bias gradient holo_channel_sum_f32.
+ * ---------------------------------------------------------------------------------------- */
+/* MaxPool2d(2,2,ceil_mode=True) on NHWC, unfused (training keeps the pre-pool activation): (B,h,w,c) -> (B,ceil(h/2),ceil(w/2),c) */
+int holo_maxpool2x2_f32(const float* x_nhwc, float* y_nhwc, int batch, int h, int w, int c, void* stream);
+/* out_padded (B, h+2*border, w+2*border, c) = the gradient of the pre-activation, zero outside the interior:
+ * dy routed through the max-pool (y_pool != NULL: dy and y_pool are (B,ceil(h/2),ceil(w/2),c); the first maximum of a window
+ * in scan order takes the gradient, as torch's stored argmax) and masked by the ReLU (relu != 0: y_act > 0); y_act (B,h,w,c) is
+ * the layer's post-ReLU, pre-pool output */
+int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float* y_pool, float* out_padded, int batch,
+                               int h, int w, int c, int relu, int border, void* stream);
+/* adjoint of ReflectionPad2d(1): dx (B,h,w,c) = interior of dxp (B,h+2*border,w+2*border,c) plus its pad ring (padded row -1
+ * onto row 1, row h onto row h-2, likewise columns); border = 1 or 2 */
+int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, void* stream);
+/* ConvTranspose2d(k2,s2)+ReLU backward helper: g (B,h,w,4c), g[..,q*c+ch] = dy[n,2Y+dy,2X+dx,ch] * (y > 0), q = dy*2+dx */
+int holo_space_to_depth2_relu_f32(const float* dy, const float* y, float* g, int batch, int h, int w, int c, int relu,
+                                  void* stream);
+/* out[c] = sum over `rows` rows of x (rows, c); c % 64 == 0 (bias gradients) */
+size_t holo_channel_sum_workspace_bytes(long rows, int c);
+int holo_channel_sum_f32(const float* x, float* out, long rows, int c, void* workspace, size_t workspace_bytes, void* stream);
+/* out[m][n][tap] = sum over the B*h*w pixels of P[pixel][m] * Q[reflect(pixel + tap)][n]: weight gradients as a GEMM whose K runs
+ * over pixels (v_mfma_f32_32x32x2_f32, deterministic).  P (B,h+2*p_border,w+2*p_border,mc) read at its interior, Q (B,h,w,nc),
+ * taps = 9 (tap = ky*3+kx, reflected neighbour: out is the OIHW gradient for m = Cout, n = Cin) or 1; mc, nc % 32 == 0 */
+size_t holo_pix_gemm_workspace_bytes(int batch, int h, int w, int mc, int nc, int taps);
+int holo_pix_gemm_f32(const float* p, int p_border, const float* q, float* out, int batch, int h, int w, int mc, int nc,
+                      int taps, void* workspace, size_t workspace_bytes, void* stream);
+/* decoder[36:38] (net.py:72-73) backward: dy (B,2,h,w) planes, x (B,h,w,64) the layer's input; dxp (B,h+2,w+2,64) = data gradient
+ * on the padded domain (fold with holo_fold_reflect_f32, border 1) or NULL; dw (2,64,3,3) + db (2) or NULL */
+size_t holo_conv_last_bwd_workspace_bytes(int batch, int h, int w);
+int holo_conv_last_bwd_f32(const float* dy, const float* x_nhwc, const float* w_oihw, float* dxp, float* dw, float* db,
+                           int batch, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+/* vgg[0:4] (net.py:77-80) backward, data gradient only (the encoder is frozen, net.py:167-170): da (B,h,w,64) the masked gradient
+ * of the ReLU'd output, din (B,1,h,w); workspace of B*(h+2)*(w+2)*4 floats */
+int holo_conv_first_dgrad_f32(const float* da, const float* w0, const float* w1, float* din, int batch, int h, int w,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* calc_mean_std (function.py:4-12) backward: dx[p][c] = dmean[c]/HW + dstd[c]*(x[p][c]-mean[c])/((HW-1)*std[c]) */
+int holo_mean_std_bwd_f32(const float* x_nhwc, const float* mean, const float* stdv, const float* dmean, const float* dstd,
+                          float* dx, int batch, int hw, int c, void* stream);
+/* Distance_G (net.py:288-308) backward, layer by layer: Linear (dx and / or dw + db), per-row norm + ReLU (z = the Linear's
+ * output), sigmoid */
+int holo_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int batch, int fin,
+                        int fout, void* stream);
+int holo_rownorm_relu_bwd_f32(const float* z, const float* dy, float* dz, int batch, int f, float eps, void* stream);
+int holo_sigmoid_bwd_f32(const float* y, const float* dy, float* dz, int n, void* stream);
 
 #ifdef __cplusplus
 }

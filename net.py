@@ -137,14 +137,16 @@ class Net(nn.Module):
         return self.mse_loss(input_mean, target_mean) + self.mse_loss(input_std, target_std)
 
     def forward(self, content, style, alpha=1.0, field_retrieval=False, unkonwn_distance=False):
-        """net.py:199-226: the training objective, FORWARD VALUES ONLY.  Same arguments (sic: ``unkonwn_distance``) and the
-        same 2 / 5 / 7 return values; every network pass runs on the HIP kernels (encoder on the style image and on the
-        generated amplitude, image-style AdaIN of function.py:15-23, two decoder passes, the distance head on both statistics);
-        the scalar MSE reductions are ``nn.MSELoss`` as in the reference.  The HIP kernels have no backward pass, so the
-        results carry no autograd graph: this evaluates the losses (validation curves, checkpoint comparison), it does not
-        train — optimising the decoder on MI355X is outside this build."""
+        """net.py:199-226: the training objective.  Same arguments (sic: ``unkonwn_distance``) and the same 2 / 5 / 7 return
+        values; every network pass runs on the HIP kernels (encoder on the style image and on the generated amplitude,
+        image-style AdaIN of function.py:15-23, two decoder passes, the distance head on both statistics); the scalar MSE
+        reductions are ``nn.MSELoss`` as in the reference.  With autograd recording (``torch.enable_grad``, parameters that
+        require gradients) the results carry a graph whose every node is a HIP kernel pair (forward / backward,
+        ``style_transfer_based_holographic_imaging_amd/autograd.py``): ``loss.backward()`` fills the gradients of the decoder and
+        of the distance head, like the reference's aten graph (fp32; eval mode: ``Distance_G``'s Dropout is the identity).
+        Under ``torch.no_grad()`` it evaluates the values only."""
         assert 0 <= alpha <= 1
-        with torch.no_grad():
+        with torch.no_grad():       # the encoder is frozen and the inputs carry no gradient: the AdaIN target is a constant (net.py:188,194)
             style_feats = self.encode_with_intermediate(style)
             content_feat = self.encode(content)
             # adain(content_feat, style_feats[-1]) and the alpha blend, in one launch (function.py:15-23, net.py:203-204)
@@ -152,22 +154,24 @@ class Net(nn.Module):
             s_mean, s_std = ops.channel_mean_std(ops.to_nhwc(style_feats[-1]))
             c_mean, c_std = ops.channel_mean_std(x)
             t = ops.as_nchw_view(ops.adain_apply(x, c_mean, c_std, s_mean, s_std, float(alpha)))
-            style_re = self.decoder(style_feats[-1])[:, :1]
-            g_t = self.decoder(t)                 # content diffraction pattern -> style diffraction pattern
-            g_t_phase = g_t[:, 1:]
-            g_t = g_t[:, :1]
-            g_t_feats = self.encode_with_intermediate(g_t)
-            loss_c = self.calc_content_loss(g_t_feats[-1], t)
-            loss_s = self.calc_style_loss(g_t_feats[0], style_feats[0])
-            for i in range(1, self.n_layer):
-                loss_s += self.calc_style_loss(g_t_feats[i], style_feats[i])
-            if field_retrieval:
-                if unkonwn_distance:
-                    d_content = self.distance_g(calc_mean_std(content_feat))
-                    d_style = self.distance_g(calc_mean_std(style_feats[-1]))
-                    return loss_c, loss_s, g_t, g_t_phase, style_re, d_content, d_style
-                return loss_c, loss_s, g_t, g_t_phase, style_re
-            return loss_c, loss_s
+        # from here on autograd records (when enabled): two decoder passes, the encoder on the generated amplitude, the losses.
+        # Every step is an autograd Function on the HIP kernels (style_transfer_based_holographic_imaging_amd/autograd.py).
+        style_re = self.decoder(style_feats[-1])[:, :1]
+        g_t = self.decoder(t)                 # content diffraction pattern -> style diffraction pattern
+        g_t_phase = g_t[:, 1:]
+        g_t = g_t[:, :1]
+        g_t_feats = self.encode_with_intermediate(g_t)
+        loss_c = self.calc_content_loss(g_t_feats[-1], t)
+        loss_s = self.calc_style_loss(g_t_feats[0], style_feats[0])
+        for i in range(1, self.n_layer):
+            loss_s += self.calc_style_loss(g_t_feats[i], style_feats[i])
+        if field_retrieval:
+            if unkonwn_distance:
+                d_content = self.distance_g(calc_mean_std(content_feat))
+                d_style = self.distance_g(calc_mean_std(style_feats[-1]))
+                return loss_c, loss_s, g_t, g_t_phase, style_re, d_content, d_style
+            return loss_c, loss_s, g_t, g_t_phase, style_re
+        return loss_c, loss_s
 
     def field_retrieval(self, content, style_feats, alpha=1.0, unknown_distance=False):
         assert 0 <= alpha <= 1
@@ -216,6 +220,10 @@ class Distance_G(nn.Module):
         if self.training:
             raise NotImplementedError("Distance_G runs in eval mode only on this path (Dropout is the identity)")
         b, c = m.shape[:2]
+        if torch.is_grad_enabled() and (m.requires_grad or s.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from style_transfer_based_holographic_imaging_amd import autograd as _ag
+            return _ag.DistanceHead.apply(m.reshape(b, c), s.reshape(b, c), self.l1.weight, self.l1.bias, self.l2.weight, self.l2.bias,
+                                          self.l3.weight, self.l3.bias, self.out.weight, self.out.bias)
         sd = {f"{n}.{p}": getattr(getattr(self, n), p) for n in ("l1", "l2", "l3", "out") for p in ("weight", "bias")}
         return ops.distance_head(m.reshape(b, c).float(), s.reshape(b, c).float(), sd)
 

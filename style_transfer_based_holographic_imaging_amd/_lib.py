@@ -77,11 +77,27 @@ SIGNATURES = {
     "holo_cast_bf16_to_f32": (_i, [_p, _p, _l, _p]),
     "holo_nhwc_to_nchw_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     "holo_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p]),
+    # backward pass (ABI 5)
+    "holo_maxpool2x2_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "holo_relu_pool_bwd_pad_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "holo_fold_reflect_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "holo_space_to_depth2_relu_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "holo_channel_sum_workspace_bytes": (_z, [_l, _i]),
+    "holo_channel_sum_f32": (_i, [_p, _p, _l, _i, _p, _z, _p]),
+    "holo_pix_gemm_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "holo_pix_gemm_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "holo_conv_last_bwd_workspace_bytes": (_z, [_i, _i, _i]),
+    "holo_conv_last_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "holo_conv_first_dgrad_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "holo_mean_std_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_linear_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_rownorm_relu_bwd_f32": (_i, [_p, _p, _p, _i, _i, _f, _p]),
+    "holo_sigmoid_bwd_f32": (_i, [_p, _p, _p, _i, _p]),
 }
 
 ASM_IN_AMP_PHASE, ASM_IN_COMPLEX = 0, 1
 ASM_OUT_AMP_PHASE, ASM_OUT_INTENSITY, ASM_OUT_COMPLEX = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HoloLibraryError(RuntimeError):

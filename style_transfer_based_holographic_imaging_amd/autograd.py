@@ -1,0 +1,206 @@
+"""torch.autograd Functions over the HIP kernels: the backward pass of the training objective.
+
+The reference trains its decoder and distance head by differentiating ``Net.forward`` (net.py:199-226, losses net.py:186-197)
+with torch.autograd over aten ops.  Here every step of a layer plan (``engine.Step``) is one ``torch.autograd.Function`` whose
+forward AND backward are C-ABI calls (include/holo_hip.h, ABI 5; csrc/backward.hip):
+
+  conv step      ReflPad + Conv3x3 [+ ReLU] [+ MaxPool ceil]
+                 dX = fold_reflect( forward_conv( pad2(route/mask(dY)), flip(W)^T ) )      the data gradient runs on the FORWARD kernels
+                 dW = pix_gemm(pad2(...), X, 9 taps),  db = channel_sum
+  convt step     ConvTranspose k2s2 [+ ReLU]:  G = space_to_depth(mask(dY));  dX = 1x1 conv of G (a centre-only 3x3 on the forward
+                 kernel);  dW = pix_gemm(X, G, 1 tap)
+  first / last   the skinny layers: VALU kernels (first: data gradient only, the encoder is frozen, net.py:167-170)
+  mean_std       calc_mean_std (function.py:4-12)
+  distance head  Linear / per-row norm + ReLU / sigmoid, layer by layer (net.py:288-308)
+
+fp32 only.  View ops (permute, reshape, slicing), ``torch.cat`` of the two statistics, the weight flips / transposes feeding the
+packers and the scalar MSE reductions (``nn.MSELoss``, as in the reference) stay torch's own: plumbing, no arithmetic of the path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+WINO_MIN_ITEMS = 128
+
+
+def _conv_fwd(x_nhwc, w_oihw, bias, relu, allow_wino=True):
+    """forward 3x3 convolution (reflection padding) of an NHWC fp32 tensor with an OIHW weight, on the Winograd kernel where the
+    layer fills the chip, else the implicit-GEMM kernel"""
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    b, h, w, _ = x_nhwc.shape
+    items = b * ((h + 31) // 32) * ((w + 15) // 16) * (cout // 32)
+    if allow_wino and cin >= 32 and cin % 16 == 0 and cout % 32 == 0 and items >= WINO_MIN_ITEMS:
+        return ops.conv3x3_wino(x_nhwc, ops.pack_conv3x3_wino(w_oihw), bias, cout, relu, False)
+    return ops.conv3x3(x_nhwc, ops.pack_conv3x3(w_oihw, torch.float32), bias, cout, relu, False)
+
+
+class ConvStep(torch.autograd.Function):
+    """ReflectionPad2d(1) -> Conv2d(3x3) [-> ReLU] [-> MaxPool2d(2,2,ceil_mode=True)], NHWC fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, pool):
+        w = weight.detach()
+        y_act = _conv_fwd(x.detach(), w, bias.detach().float().contiguous(), relu)
+        y = ops.maxpool2x2(y_act) if pool else y_act
+        ctx.relu, ctx.pool = relu, pool
+        ctx.save_for_backward(x.detach(), w, y_act if (relu or pool) else None, y if pool else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y_act, y_pool = ctx.saved_tensors
+        b, h, wd, cin = x.shape
+        cout = w.shape[0]
+        if y_act is None:
+            y_act = x.new_empty((b, h, wd, cout))       # shape carrier only (neither ReLU nor pool reads it)
+        dap = ops.relu_pool_bwd_pad(dy.contiguous(), y_act, y_pool, ctx.relu, 2)          # (B, h+4, w+4, Cout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if cin % 64 != 0:
+                raise NotImplementedError(f"data gradient of a {cin} -> {cout} convolution: the forward kernels need Cout % 64 == 0")
+            wd_t = w.flip(2, 3).transpose(0, 1).contiguous()                               # (Cin, Cout, 3, 3): full correlation
+            dxp = _conv_fwd(dap, wd_t, torch.zeros(cin, device=x.device), False)          # (B, h+4, w+4, Cin)
+            dx = ops.fold_reflect(dxp, h, wd, 2)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = ops.pix_gemm(dap, 2, x, 9).view(cout, cin, 3, 3)
+            db = ops.channel_sum(dap)
+        return dx, dw, db, None, None
+
+
+class ConvTStep(torch.autograd.Function):
+    """ConvTranspose2d(k=2, s=2) [-> ReLU], NHWC fp32; weight (Cin, Cout, 2, 2)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        w = weight.detach()
+        cout = w.shape[1]
+        y = ops.convt2x2(x.detach(), ops.pack_convt2x2(w, torch.float32), bias.detach().float().contiguous(), cout, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x.detach(), w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        b, h, wd, cin = x.shape
+        cout = w.shape[1]
+        g = ops.space_to_depth2_relu(dy.contiguous(), y, ctx.relu)                        # (B, h, w, 4*Cout), channel q*Cout + co
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if cin % 64 != 0:
+                raise NotImplementedError("data gradient of the transposed convolution needs Cin % 64 == 0")
+            w3 = torch.zeros((cin, 4 * cout, 3, 3), dtype=torch.float32, device=x.device)  # a 1x1 convolution as a centre-only 3x3
+            w3[:, :, 1, 1] = w.permute(0, 2, 3, 1).reshape(cin, 4 * cout)
+            dx = _conv_fwd(g, w3, torch.zeros(cin, device=x.device), False)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = ops.pix_gemm(x, 0, g, 1).view(cin, 2, 2, cout).permute(0, 3, 1, 2).contiguous()
+            db = ops.channel_sum(g).view(4, cout).sum(0)
+        return dx, dw, db, None
+
+
+class FirstStep(torch.autograd.Function):
+    """vgg[0:4]: Conv2d(1,3,1x1) -> ReflPad -> Conv2d(3,64,3x3) -> ReLU; frozen (net.py:167-170): data gradient only."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1):
+        y = ops.conv_first(x.detach(), w0.detach(), b0.detach(), w1.detach(), b1.detach(), out_dtype=torch.float32)
+        ctx.save_for_backward(w0.detach(), w1.detach(), y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w0, w1, y = ctx.saved_tensors
+        if any(ctx.needs_input_grad[1:]):
+            raise NotImplementedError("the first encoder layer is frozen on this path (net.py:167-170): no weight gradient")
+        da = ops.relu_pool_bwd_pad(dy.contiguous(), y, None, True, 0)
+        return ops.conv_first_dgrad(da, w0, w1), None, None, None, None
+
+
+class LastStep(torch.autograd.Function):
+    """decoder[36:38]: ReflPad -> Conv2d(64, 2, 3x3), NHWC in, (B,2,H,W) planes out."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x.detach(), weight.detach())
+        return ops.conv_last(x.detach(), weight.detach().float().contiguous(), bias.detach().float().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dw, db = ops.conv_last_bwd(dy.contiguous(), x, w, need_dx=ctx.needs_input_grad[0], need_dw=need_dw)
+        return dx, dw, db
+
+
+class MeanStd(torch.autograd.Function):
+    """calc_mean_std (function.py:4-12) on NHWC fp32 -> ((B,C), (B,C))."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        mean, std = ops.channel_mean_std(x.detach(), eps)
+        ctx.save_for_backward(x.detach(), mean, std)
+        return mean, std
+
+    @staticmethod
+    def backward(ctx, dmean, dstd):
+        x, mean, std = ctx.saved_tensors
+        return ops.mean_std_bwd(x, mean, std, dmean.contiguous(), dstd.contiguous()), None
+
+
+class DistanceHead(torch.autograd.Function):
+    """Distance_G.forward (net.py:288-308) on (mean, std) of shape (B,512): three Linear -> per-row norm -> ReLU, then
+    sigmoid(Linear).  Gradients for the eight parameters and the two inputs."""
+
+    @staticmethod
+    def forward(ctx, mean, std, w1, b1, w2, b2, w3, b3, wo, bo):
+        x0 = torch.cat([mean.detach(), std.detach()], 1).float().contiguous()
+        ps = [t.detach().float().contiguous() for t in (w1, b1, w2, b2, w3, b3, wo, bo)]
+        z1 = ops.linear(x0, ps[0], ps[1])
+        a1 = ops.rownorm_relu(z1)
+        z2 = ops.linear(a1, ps[2], ps[3])
+        a2 = ops.rownorm_relu(z2)
+        z3 = ops.linear(a2, ps[4], ps[5])
+        a3 = ops.rownorm_relu(z3)
+        y = ops.linear1_sigmoid(a3, ps[6], ps[7])
+        ctx.save_for_backward(x0, z1, a1, z2, a2, z3, a3, y, ps[0], ps[2], ps[4], ps[6])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, z1, a1, z2, a2, z3, a3, y, w1, w2, w3, wo = ctx.saved_tensors
+        dz4 = ops.sigmoid_bwd(y, dy.contiguous())
+        da3, dwo, dbo = ops.linear_bwd(dz4, a3, wo)
+        dz3 = ops.rownorm_relu_bwd(z3, da3)
+        da2, dw3, db3 = ops.linear_bwd(dz3, a2, w3)
+        dz2 = ops.rownorm_relu_bwd(z2, da2)
+        da1, dw2, db2 = ops.linear_bwd(dz2, a1, w2)
+        dz1 = ops.rownorm_relu_bwd(z1, da1)
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dx0, dw1, db1 = ops.linear_bwd(dz1, x0, w1, need_dx=need_in)
+        c = x0.shape[1] // 2
+        dmean = dx0[:, :c].contiguous() if need_in else None
+        dstd = dx0[:, c:].contiguous() if need_in else None
+        return dmean, dstd, dw1, db1, dw2, db2, dw3, db3, dwo, dbo
+
+
+def needs_graph(x, *modules):
+    """True when autograd is recording and the input or one of the parameters asks for a gradient."""
+    if not torch.is_grad_enabled():
+        return False
+    if isinstance(x, torch.Tensor) and x.requires_grad:
+        return True
+    return any(p.requires_grad for m in modules if m is not None for p in m.parameters())
+
+
+def run_step(step, x):
+    """one engine.Step through its autograd Function (fp32)"""
+    conv = step.conv
+    if step.kind == "first":
+        return FirstStep.apply(x, step.conv0.weight, step.conv0.bias, conv.weight, conv.bias)
+    if step.kind == "conv":
+        return ConvStep.apply(x, conv.weight, conv.bias, bool(step.relu), bool(step.pool))
+    if step.kind == "convt":
+        return ConvTStep.apply(x, conv.weight, conv.bias, bool(step.relu))
+    return LastStep.apply(x, conv.weight, conv.bias)

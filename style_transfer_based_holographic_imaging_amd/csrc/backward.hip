@@ -1,0 +1,675 @@
+// Backward pass of the training objective (Net.forward, net.py:199-226; losses net.py:186-197), fp32, NHWC.
+//
+// The reference trains the decoder (and the distance head) through torch.autograd over aten ops.  Here every backward op of the
+// path is a HIP kernel behind the C-ABI, built so that the heavy products reuse the forward machinery:
+//
+//   * data gradient of ReflectionPad2d(1) + Conv2d(3x3):  dXp = full correlation of dA with the flipped, transposed weights on the
+//     PADDED domain, then the adjoint of the reflection folds the pad ring back (row -1 onto row 1, row H onto row H-2).  The
+//     correlation is the FORWARD convolution kernel (Winograd / implicit GEMM, conv_winograd.hip / conv_mfma.hip) run on dA embedded
+//     in a zero border of TWO pixels: the forward kernel's own reflection then only ever mirrors zeros.  relu_pool_bwd_pad_kernel
+//     builds that embedded tensor (ReLU mask and max-pool routing applied on the way), fold_reflect_kernel does the fold.
+//   * weight gradient: dW[m][n][tap] = sum over pixels of P[pixel][m] * Q[pixel + tap][n] — a GEMM whose K runs over PIXELS
+//     (pix_gemm_kernel, v_mfma_f32_32x32x2_f32, operands straight from global memory: a pixel's channels are contiguous, so a
+//     lane group's 32 channels of one pixel are one 128-byte segment).  Partial sums per (pixel range, wave) go to a workspace
+//     and are added in a fixed order (deterministic, like the split-K forward).
+//   * ConvTranspose2d(k2,s2): its data gradient is a 1x1 convolution of the space-to-depth gradient (B,H,W,4*Cout) — run as a
+//     3x3 forward convolution with a centre-only kernel; its weight gradient is pix_gemm with one tap.
+//   * the skinny layers (3 -> 64 first, 64 -> 2 last), statistics and the distance head: small VALU kernels.
+//
+// Everything is exact fp32 arithmetic; results differ from torch.autograd by summation order only (tests/test_hip_backward.py).
+#include "common.h"
+
+namespace holo {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ---- MaxPool2d(2,2,ceil_mode=True), unfused (training keeps the pre-pool activation for the backward routing) ----------------
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int c4,
+                                                         int ho, int wo, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cq = (int)(i % c4);
+    long r = i / c4;
+    const int X = (int)(r % wo);
+    r /= wo;
+    const int Y = (int)(r % ho);
+    const long n = r / ho;
+    const float4* xi = reinterpret_cast<const float4*>(x) + n * h * (long)w * c4;
+    float4 m = xi[((long)(2 * Y) * w + 2 * X) * c4 + cq];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const int yy = 2 * Y + (k >> 1), xx = 2 * X + (k & 1);
+        if (yy < h && xx < w) {
+            const float4 v = xi[((long)yy * w + xx) * c4 + cq];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    reinterpret_cast<float4*>(y)[i] = m;
+}
+
+// ---- dA = route(dy) * mask, embedded in a zero border -------------------------------------------------------------------------
+// out: (B, h + 2*border, w + 2*border, c), zero outside the interior.  Interior pixel (y, x):
+//   g = pool ? (y_act[y,x] is the FIRST maximum of its 2x2 window in scan order ? dy[y/2, x/2] : 0) : dy[y, x]
+//   out = relu ? (y_act > 0 ? g : 0) : g                      (torch: max_pool2d_backward routes to the stored argmax, the first
+//                                                              strict maximum; threshold_backward masks with the output > 0)
+__global__ __launch_bounds__(256) void relu_pool_bwd_pad_kernel(const float* __restrict__ dy, const float* __restrict__ y_act,
+                                                                const float* __restrict__ y_pool, float* __restrict__ out, int h,
+                                                                int w, int c4, int relu, int border, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int hp = h + 2 * border, wp = w + 2 * border;
+    const int cq = (int)(i % c4);
+    long r = i / c4;
+    const int xp = (int)(r % wp);
+    r /= wp;
+    const int yp = (int)(r % hp);
+    const long n = r / hp;
+    const int y = yp - border, x = xp - border;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y >= 0 && y < h && x >= 0 && x < w) {
+        const float4* ya = reinterpret_cast<const float4*>(y_act) + n * h * (long)w * c4;
+        const float4 a = relu || y_pool ? ya[((long)y * w + x) * c4 + cq] : g;
+        if (y_pool) {
+            const int ho = (h + 1) >> 1, wo = (w + 1) >> 1;
+            const long po = (n * ho + (y >> 1)) * (long)wo + (x >> 1);
+            const float4 m = reinterpret_cast<const float4*>(y_pool)[po * c4 + cq];
+            const float4 d = reinterpret_cast<const float4*>(dy)[po * c4 + cq];
+            // earlier members of the window (scan order) that already hold the maximum take the gradient instead
+            bool e0 = false, e1 = false, e2 = false, e3 = false;
+            const int k = ((y & 1) << 1) | (x & 1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q < k) {
+                    const int yy = (y & ~1) + (q >> 1), xx = (x & ~1) + (q & 1);     // always inside the image for q < k
+                    const float4 v = ya[((long)yy * w + xx) * c4 + cq];
+                    e0 |= v.x == m.x; e1 |= v.y == m.y; e2 |= v.z == m.z; e3 |= v.w == m.w;
+                }
+            }
+            g.x = (a.x == m.x && !e0) ? d.x : 0.f;
+            g.y = (a.y == m.y && !e1) ? d.y : 0.f;
+            g.z = (a.z == m.z && !e2) ? d.z : 0.f;
+            g.w = (a.w == m.w && !e3) ? d.w : 0.f;
+        } else {
+            g = reinterpret_cast<const float4*>(dy)[((n * h + y) * (long)w + x) * c4 + cq];
+        }
+        if (relu) {
+            g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+        }
+    }
+    reinterpret_cast<float4*>(out)[i] = g;
+}
+
+// ---- adjoint of ReflectionPad2d(1): fold the pad ring of dXp (padded coordinates -1 .. h at index + border) onto the interior ----
+__global__ __launch_bounds__(256) void fold_reflect_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int h, int w, int c4,
+                                                           int border, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cq = (int)(i % c4);
+    long r = i / c4;
+    const int x = (int)(r % w);
+    r /= w;
+    const int y = (int)(r % h);
+    const long n = r / h;
+    const int hp = h + 2 * border, wp = w + 2 * border;
+    const float4* src = reinterpret_cast<const float4*>(dxp) + n * hp * (long)wp * c4;
+    // padded rows that reflect onto row y: y itself, -1 if y == 1, h if y == h - 2
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y;
+    if (y == 1) ys[ny++] = -1;
+    if (y == h - 2) ys[ny++] = h;
+    xs[nx++] = x;
+    if (x == 1) xs[nx++] = -1;
+    if (x == w - 2) xs[nx++] = w;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            const float4 v = src[((long)(ys[a] + border) * wp + xs[b] + border) * c4 + cq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    reinterpret_cast<float4*>(dx)[i] = s;
+}
+
+// ---- ConvTranspose2d(k2,s2) backward helper: G[n,Y,X,q*c + ch] = dy[n,2Y+dy,2X+dx,ch] * (y > 0), q = dy*2+dx ----------------
+__global__ __launch_bounds__(256) void space_to_depth2_relu_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                   float* __restrict__ g, int h, int w, int c4, int relu, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cq = (int)(i % c4);
+    long r = i / c4;
+    const int q = (int)(r & 3);
+    r >>= 2;
+    const int X = (int)(r % w);
+    r /= w;
+    const int Y = (int)(r % h);
+    const long n = r / h;
+    const long src = ((n * (2 * h) + 2 * Y + (q >> 1)) * (long)(2 * w) + 2 * X + (q & 1)) * c4 + cq;
+    float4 v = reinterpret_cast<const float4*>(dy)[src];
+    if (relu) {
+        const float4 a = reinterpret_cast<const float4*>(y)[src];
+        v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+    }
+    reinterpret_cast<float4*>(g)[i] = v;     // i = ((n*h + Y)*w + X)*4*c4 + q*c4 + cq
+}
+
+// ---- sum over pixels per channel (bias gradients): x (rows, c) -> out[c]; deterministic two-stage ------------------------------
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, double* __restrict__ part, long rows,
+                                                                  int c, int parts) {
+    // grid (c / 64, parts): 16 lanes x float4 = 64 channels of a row, 16 row groups per block
+    __shared__ double s_sum[16][64];
+    const int tid = threadIdx.x, cq = tid & 15, pg = tid >> 4;
+    const int c0 = blockIdx.x * 64;
+    const long per = (rows + parts - 1) / parts;
+    const long r0 = (long)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    double s[4] = {0, 0, 0, 0};
+    for (long p = r0 + pg; p < r1; p += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(x + p * c + c0 + 4 * cq);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_sum[pg][4 * cq + j] = s[j];
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0;
+        for (int g = 0; g < 16; ++g) t += s_sum[g][tid];
+        part[(long)blockIdx.y * c + c0 + tid] = t;
+    }
+}
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const double* __restrict__ part, float* __restrict__ out, int c, int parts) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    double t = 0;
+    for (int p = 0; p < parts; ++p) t += part[(long)p * c + ch];
+    out[ch] = (float)t;
+}
+
+// ---- pixel-K GEMM: out[m][n][tap] = sum over pixels P[pixel][m] * Q[reflect(pixel + tap)][n] -----------------------------------
+// P: (B, h + 2*pb, w + 2*pb, mc) (the embedded gradient; interior read), Q: (B, h, w, nc).  Block = 4 waves on one 32 x 32 (m, n)
+// tile; blockIdx.z and the wave index split the image rows; every (split, wave) writes its own partial tile, pix_gemm_reduce adds
+// them in order.  v_mfma_f32_32x32x2_f32: A lane (m = lane & 31, k = lane >> 5), B lane (k, n): k = two neighbouring pixels.
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void pix_gemm_kernel(const float* __restrict__ p, int pb, const float* __restrict__ q,
+                                                          float* __restrict__ part, int batch, int h, int w, int mc, int nc,
+                                                          int rows_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hs = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const long slot = (long)blockIdx.z * 4 + wave;                    // partial index
+    const long row0 = slot * rows_per_wave;                           // image rows (n * h + y) of this wave
+    const long rows_total = (long)batch * h;
+    long row1 = row0 + rows_per_wave;
+    if (row1 > rows_total) row1 = rows_total;
+    floatx16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    const int hp = h + 2 * pb, wp = w + 2 * pb;
+    for (long row = row0; row < row1; ++row) {
+        const long n = row / h;
+        const int y = (int)(row % h);
+        const float* __restrict__ prow = p + ((n * hp + y + pb) * (long)wp + pb) * mc + m0 + r;
+        const float* qrow[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ry = TAPS == 9 ? reflect1(y + dy - 1, h) : y;
+            qrow[dy] = q + (n * h + ry) * (long)w * nc + n0 + r;
+        }
+        for (int x = 0; x < w; x += 2) {
+            const int xx = x + hs;
+            const bool ok = xx < w;
+            const float a = ok ? prow[(long)xx * mc] : 0.0f;
+            if constexpr (TAPS == 9) {
+                int rx[3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) rx[dx] = reflect1(xx + dx - 1, w);
+                float b[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) b[t] = qrow[t / 3][(long)rx[t % 3] * nc];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+            } else {
+                const float b = qrow[0][(long)(ok ? xx : 0) * nc];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+            }
+        }
+    }
+    // D[m][n]: m = (i & 3) + 8 * (i >> 2) + 4 * hs, n = r.  Partial layout [slot][m][n][tap] over the FULL (mc, nc) matrix.
+    float* __restrict__ dst = part + slot * (long)mc * nc * TAPS;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = (i & 3) + 8 * (i >> 2) + 4 * hs;
+            dst[((long)(m0 + m) * nc + n0 + r) * TAPS + t] = acc[t][i];
+        }
+}
+__global__ __launch_bounds__(256) void pix_gemm_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long elems, int slots) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    float s = 0.0f;
+    for (int k = 0; k < slots; ++k) s += part[(long)k * elems + i];
+    out[i] = s;
+}
+
+// ---- last layer (ReflPad + Conv2d(64, 2, 3x3), no activation; NHWC in, NCHW planes out), backward ------------------------------
+// data gradient on the padded domain: dxp[i][j][ci] = sum_tap sum_co dy[co][i - dy][j - dx] * w[co][ci][tap]   (then fold_reflect)
+__global__ __launch_bounds__(256) void conv_last_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ dxp, int h, int wd, long total) {
+    // dxp: (B, h + 2, wd + 2, 64), border 1; thread = (padded pixel, channel quad)
+    __shared__ float ws[2 * 64 * 9];
+    for (int i = threadIdx.x; i < 2 * 64 * 9; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cq = (int)(i & 15);
+    long r = i >> 4;
+    const int wp = wd + 2, hp = h + 2;
+    const int jp = (int)(r % wp);
+    r /= wp;
+    const int ip = (int)(r % hp);
+    const long n = r / hp;
+    const float* __restrict__ d0 = dy + n * 2 * h * (long)wd;
+    const float* __restrict__ d1 = d0 + h * (long)wd;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int y = ip - 1 - (t / 3 - 1), x = jp - 1 - (t % 3 - 1);     // output pixel whose tap t reads padded pixel (ip-1, jp-1)
+        if (y >= 0 && y < h && x >= 0 && x < wd) {
+            const float g0 = d0[(long)y * wd + x], g1 = d1[(long)y * wd + x];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = 4 * cq + k;
+                s[k] += g0 * ws[(0 * 64 + ci) * 9 + t] + g1 * ws[(1 * 64 + ci) * 9 + t];
+            }
+        }
+    }
+    reinterpret_cast<float4*>(dxp)[i] = make_float4(s[0], s[1], s[2], s[3]);
+}
+// weight / bias gradient partials: block b takes a range of image rows; thread t < 1152 + 2 owns one (co, ci, tap) (or a bias)
+__global__ __launch_bounds__(384) void conv_last_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ part, int batch, int h, int wd, int rows_per_block) {
+    const long rows_total = (long)batch * h;
+    const long row0 = (long)blockIdx.x * rows_per_block;
+    long row1 = row0 + rows_per_block;
+    if (row1 > rows_total) row1 = rows_total;
+    // thread -> (tap, co, ci): ci fastest so that a wave reads 64 contiguous channels
+    float acc[3] = {0.f, 0.f, 0.f};
+    float bacc = 0.f;
+    for (long row = row0; row < row1; ++row) {
+        const long n = row / h;
+        const int y = (int)(row % h);
+        const float* __restrict__ d = dy + n * 2 * h * (long)wd;
+        for (int xq = 0; xq < wd; ++xq) {
+            const float g[2] = {d[(long)y * wd + xq], d[h * (long)wd + (long)y * wd + xq]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int o = threadIdx.x + k * 384;      // 0 .. 1151 = tap * 128 + co * 64 + ci
+                const int t = o >> 7, co = (o >> 6) & 1, ci = o & 63;
+                const int ry = reflect1(y + t / 3 - 1, h), rx = reflect1(xq + t % 3 - 1, wd);
+                acc[k] += g[co] * x[((n * h + ry) * (long)wd + rx) * 64 + ci];
+            }
+            if (threadIdx.x < 2) bacc += g[threadIdx.x];
+        }
+    }
+    float* __restrict__ dst = part + (long)blockIdx.x * 1154;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dst[threadIdx.x + k * 384] = acc[k];
+    if (threadIdx.x < 2) dst[1152 + threadIdx.x] = bacc;
+}
+__global__ __launch_bounds__(256) void conv_last_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                    float* __restrict__ db, int blocks) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= 1154) return;
+    double s = 0;
+    for (int b = 0; b < blocks; ++b) s += part[(long)b * 1154 + o];
+    if (o >= 1152) { db[o - 1152] = (float)s; return; }
+    const int t = o >> 7, co = (o >> 6) & 1, ci = o & 63;
+    dw[(co * 64 + ci) * 9 + t] = (float)s;             // OIHW (2, 64, 3, 3)
+}
+
+// ---- first layer (Conv2d(1,3,1x1) -> ReflPad -> Conv2d(3,64,3x3) -> ReLU; frozen encoder): gradient of its INPUT plane --------
+// da: (B, h, w, 64) masked gradient of the ReLU'd output.  d3p[i][j][c] = sum_tap sum_co da[i - dy][j - dx][co] * w1[co][c][tap] on
+// the padded domain (border 1), folded by the reflection's adjoint, then din = sum_c w0[c] * d3.
+__global__ __launch_bounds__(256) void conv_first_dgrad_pad_kernel(const float* __restrict__ da, const float* __restrict__ w1,
+                                                                   float* __restrict__ d3p, int h, int wd, long total) {
+    __shared__ float ws[64 * 27];
+    for (int i = threadIdx.x; i < 64 * 27; i += 256) ws[i] = w1[i];
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // padded pixel
+    if (i >= total) return;
+    const int wp = wd + 2, hp = h + 2;
+    long r = i;
+    const int jp = (int)(r % wp);
+    r /= wp;
+    const int ip = (int)(r % hp);
+    const long n = r / hp;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int t = 0; t < 9; ++t) {
+        const int y = ip - 1 - (t / 3 - 1), x = jp - 1 - (t % 3 - 1);
+        if (y >= 0 && y < h && x >= 0 && x < wd) {
+            const float4* g = reinterpret_cast<const float4*>(da + ((n * h + y) * (long)wd + x) * 64);
+#pragma unroll 4
+            for (int cq = 0; cq < 16; ++cq) {
+                const float4 v = g[cq];
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int co = 4 * cq + k;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) s[c] += vv[k] * ws[co * 27 + c * 9 + t];
+                }
+            }
+        }
+    }
+    float* o = d3p + i * 4;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 0.f;       // (B, h+2, w+2, 4): channel 3 is padding
+}
+__global__ __launch_bounds__(256) void conv_first_dgrad_fold_kernel(const float* __restrict__ d3p, const float* __restrict__ w0,
+                                                                    float* __restrict__ din, int h, int w, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    long r = i;
+    const int x = (int)(r % w);
+    r /= w;
+    const int y = (int)(r % h);
+    const long n = r / h;
+    const int hp = h + 2, wp = w + 2;
+    const float4* src = reinterpret_cast<const float4*>(d3p) + n * hp * (long)wp;
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y;
+    if (y == 1) ys[ny++] = -1;
+    if (y == h - 2) ys[ny++] = h;
+    xs[nx++] = x;
+    if (x == 1) xs[nx++] = -1;
+    if (x == w - 2) xs[nx++] = w;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            const float4 v = src[(long)(ys[a] + 1) * wp + xs[b] + 1];
+            s0 += v.x; s1 += v.y; s2 += v.z;
+        }
+    din[i] = w0[0] * s0 + w0[1] * s1 + w0[2] * s2;
+}
+
+// ---- calc_mean_std backward (function.py:4-12): mean = sum x / HW, std = sqrt(var_unbiased + eps) ----------------------------
+// dx[p][c] = dmean[c] / HW + dstd[c] * (x[p][c] - mean[c]) / ((HW - 1) * std[c])
+__global__ __launch_bounds__(256) void mean_std_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ stdv, const float* __restrict__ dmean,
+                                                           const float* __restrict__ dstd, float* __restrict__ dx, int hw, int c4,
+                                                           long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cq = (int)(i % c4);
+    const long n = i / ((long)hw * c4);
+    const long sc = n * c4 + cq;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 m = reinterpret_cast<const float4*>(mean)[sc], s = reinterpret_cast<const float4*>(stdv)[sc];
+    const float4 dm = reinterpret_cast<const float4*>(dmean)[sc], ds = reinterpret_cast<const float4*>(dstd)[sc];
+    const float ihw = 1.0f / (float)hw, ih1 = 1.0f / (float)(hw - 1);
+    float4 o;
+    o.x = dm.x * ihw + ds.x * (v.x - m.x) * ih1 / s.x;
+    o.y = dm.y * ihw + ds.y * (v.y - m.y) * ih1 / s.y;
+    o.z = dm.z * ihw + ds.z * (v.z - m.z) * ih1 / s.z;
+    o.w = dm.w * ihw + ds.w * (v.w - m.w) * ih1 / s.w;
+    reinterpret_cast<float4*>(dx)[i] = o;
+}
+
+// ---- distance head backward (net.py:288-308): Linear, per-row norm + ReLU, sigmoid -------------------------------------------
+// Linear y = x W^T + b with x (B, fin), W (fout, fin): dx = dy W; dW = dy^T x; db = sum_b dy.  The head is tiny (B x 1024):
+// one thread per output element.
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int b, int fin, int fout) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (row, input feature)
+    if (i >= b * fin) return;
+    const int row = i / fin, k = i % fin;
+    float s = 0.f;
+    for (int o = 0; o < fout; ++o) s += dy[row * fout + o] * w[(long)o * fin + k];
+    dx[i] = s;
+}
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            float* __restrict__ dw, float* __restrict__ db, int b, int fin, int fout) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // (output feature, input feature)
+    if (i >= (long)fout * fin) return;
+    const int o = (int)(i / fin), k = (int)(i % fin);
+    float s = 0.f;
+    for (int row = 0; row < b; ++row) s += dy[row * fout + o] * x[row * fin + k];
+    dw[i] = s;
+    if (k == 0) {
+        float t = 0.f;
+        for (int row = 0; row < b; ++row) t += dy[row * fout + o];
+        db[o] = t;
+    }
+}
+// y = relu((z - mean_row) / sqrt(var_row_biased + eps)): one block per row
+__global__ __launch_bounds__(256) void rownorm_relu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                               float* __restrict__ dz, int f, float eps) {
+    __shared__ double red[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* zr = z + (long)row * f;
+    const float* dr = dy + (long)row * f;
+    double s = 0;
+    for (int k = tid; k < f; k += 256) s += zr[k];
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    const double mean = red[0] / f;
+    __syncthreads();
+    s = 0;
+    for (int k = tid; k < f; k += 256) { const double d = zr[k] - mean; s += d * d; }
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    const double inv = 1.0 / sqrt(red[0] / f + (double)eps);
+    __syncthreads();
+    // g = dy masked by the ReLU; dz = inv * (g - mean(g) - xhat * mean(g * xhat))
+    double sg = 0, sgx = 0;
+    for (int k = tid; k < f; k += 256) {
+        const double xh = (zr[k] - mean) * inv;
+        const double g = xh > 0 ? dr[k] : 0.0;
+        sg += g; sgx += g * xh;
+    }
+    red[tid] = sg;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    const double mg = red[0] / f;
+    __syncthreads();
+    red[tid] = sgx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    const double mgx = red[0] / f;
+    for (int k = tid; k < f; k += 256) {
+        const double xh = (zr[k] - mean) * inv;
+        const double g = xh > 0 ? dr[k] : 0.0;
+        dz[(long)row * f + k] = (float)(inv * (g - mg - xh * mgx));
+    }
+}
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dz, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dz[i] = dy[i] * y[i] * (1.0f - y[i]);
+}
+
+static inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
+
+// partial layout of pix_gemm: slots = ceil(rows / rows_per_wave) rounded up to a multiple of 4 (4 waves per block)
+struct PixGemmPlan {
+    int rows_per_wave, splits;
+    long slots;
+};
+static PixGemmPlan pix_gemm_plan(int batch, int h, int mc, int nc) {
+    const long rows = (long)batch * h;
+    const long tiles = (long)(mc / 32) * (nc / 32);
+    // aim at ~8 blocks per CU over the whole grid, at least 2 image rows per wave
+    long splits = (2048 + tiles - 1) / tiles;
+    if (splits < 1) splits = 1;
+    long rpw = (rows + splits * 4 - 1) / (splits * 4);
+    if (rpw < 2) rpw = 2;
+    splits = (rows + rpw * 4 - 1) / (rpw * 4);
+    PixGemmPlan p;
+    p.rows_per_wave = (int)rpw;
+    p.splits = (int)splits;
+    p.slots = splits * 4;
+    return p;
+}
+
+}  // namespace holo
+
+extern "C" {
+
+using namespace holo;
+
+int holo_maxpool2x2_f32(const float* x_nhwc, float* y_nhwc, int batch, int h, int w, int c, void* stream) {
+    HOLO_REQUIRE(x_nhwc && y_nhwc, HOLO_ERR_ARG, "holo_maxpool2x2_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, HOLO_ERR_ARG, "holo_maxpool2x2_f32: batch=%d h=%d w=%d c=%d (c %% 4)", batch, h, w, c);
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+    const long total = (long)batch * ho * wo * (c / 4);
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x_nhwc, y_nhwc, h, w, c / 4, ho, wo, total);
+    return check_launch("holo_maxpool2x2_f32");
+}
+
+int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float* y_pool, float* out_padded, int batch, int h, int w,
+                               int c, int relu, int border, void* stream) {
+    HOLO_REQUIRE(dy && out_padded && (y_act || (!relu && !y_pool)), HOLO_ERR_ARG, "holo_relu_pool_bwd_pad_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && border >= 0 && border <= 2, HOLO_ERR_ARG,
+                 "holo_relu_pool_bwd_pad_f32: batch=%d h=%d w=%d c=%d border=%d", batch, h, w, c, border);
+    const long total = (long)batch * (h + 2 * border) * (w + 2 * border) * (c / 4);
+    hipLaunchKernelGGL(relu_pool_bwd_pad_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dy, y_act, y_pool, out_padded, h, w,
+                       c / 4, relu, border, total);
+    return check_launch("holo_relu_pool_bwd_pad_f32");
+}
+
+int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, void* stream) {
+    HOLO_REQUIRE(dxp && dx, HOLO_ERR_ARG, "holo_fold_reflect_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && c > 0 && c % 4 == 0 && border >= 1 && border <= 2, HOLO_ERR_ARG,
+                 "holo_fold_reflect_f32: batch=%d h=%d w=%d c=%d border=%d (reflection padding needs h,w >= 2)", batch, h, w, c, border);
+    const long total = (long)batch * h * w * (c / 4);
+    hipLaunchKernelGGL(fold_reflect_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dxp, dx, h, w, c / 4, border, total);
+    return check_launch("holo_fold_reflect_f32");
+}
+
+int holo_space_to_depth2_relu_f32(const float* dy, const float* y, float* g, int batch, int h, int w, int c, int relu, void* stream) {
+    HOLO_REQUIRE(dy && g && (y || !relu), HOLO_ERR_ARG, "holo_space_to_depth2_relu_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, HOLO_ERR_ARG, "holo_space_to_depth2_relu_f32: batch=%d h=%d w=%d c=%d", batch, h, w, c);
+    const long total = (long)batch * h * w * 4 * (c / 4);
+    hipLaunchKernelGGL(space_to_depth2_relu_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dy, y, g, h, w, c / 4, relu, total);
+    return check_launch("holo_space_to_depth2_relu_f32");
+}
+
+size_t holo_channel_sum_workspace_bytes(long rows, int c) {
+    if (rows <= 0 || c <= 0) return 0;
+    const int parts = rows < 4096 ? 1 : (rows < (1L << 20) ? 64 : 512);
+    return (size_t)parts * c * sizeof(double);
+}
+int holo_channel_sum_f32(const float* x, float* out, long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
+    HOLO_REQUIRE(x && out && workspace, HOLO_ERR_ARG, "holo_channel_sum_f32: null pointer");
+    HOLO_REQUIRE(rows > 0 && c > 0 && c % 64 == 0, HOLO_ERR_ARG, "holo_channel_sum_f32: rows=%ld c=%d (c %% 64)", rows, c);
+    HOLO_REQUIRE(workspace_bytes >= holo_channel_sum_workspace_bytes(rows, c), HOLO_ERR_WORKSPACE, "holo_channel_sum_f32: workspace too small");
+    const int parts = rows < 4096 ? 1 : (rows < (1L << 20) ? 64 : 512);
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(c / 64, parts), dim3(256), 0, as_stream(stream), x, static_cast<double*>(workspace), rows, c, parts);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), static_cast<const double*>(workspace), out, c, parts);
+    return check_launch("holo_channel_sum_f32");
+}
+
+size_t holo_pix_gemm_workspace_bytes(int batch, int h, int w, int mc, int nc, int taps) {
+    if (batch <= 0 || h <= 0 || w <= 0 || mc <= 0 || nc <= 0 || (taps != 1 && taps != 9)) return 0;
+    const PixGemmPlan p = pix_gemm_plan(batch, h, mc, nc);
+    return (size_t)p.slots * mc * nc * taps * sizeof(float);
+}
+/* out[m][n][tap] = sum over the B*h*w pixels of P[pixel][m] * Q[reflect(pixel + tap)][n]; taps = 9 (3x3, tap = ky*3+kx, reflected
+ * neighbour) or 1 (the pixel itself).  P: (B, h + 2*p_border, w + 2*p_border, mc) NHWC read at its interior, Q: (B, h, w, nc). */
+int holo_pix_gemm_f32(const float* p, int p_border, const float* q, float* out, int batch, int h, int w, int mc, int nc, int taps,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    HOLO_REQUIRE(p && q && out && workspace, HOLO_ERR_ARG, "holo_pix_gemm_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && mc > 0 && nc > 0 && mc % 32 == 0 && nc % 32 == 0 && (taps == 1 || taps == 9) && p_border >= 0,
+                 HOLO_ERR_ARG, "holo_pix_gemm_f32: batch=%d h=%d w=%d mc=%d nc=%d taps=%d (channels %% 32, taps 1 | 9)", batch, h, w, mc, nc, taps);
+    HOLO_REQUIRE(workspace_bytes >= holo_pix_gemm_workspace_bytes(batch, h, w, mc, nc, taps), HOLO_ERR_WORKSPACE, "holo_pix_gemm_f32: workspace too small");
+    const PixGemmPlan pl = pix_gemm_plan(batch, h, mc, nc);
+    float* part = static_cast<float*>(workspace);
+    const dim3 grid(mc / 32, nc / 32, pl.splits);
+    if (taps == 9)
+        hipLaunchKernelGGL(pix_gemm_kernel<9>, grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
+    else
+        hipLaunchKernelGGL(pix_gemm_kernel<1>, grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
+    const long elems = (long)mc * nc * taps;
+    hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), part, out, elems, (int)pl.slots);
+    return check_launch("holo_pix_gemm_f32");
+}
+
+size_t holo_conv_last_bwd_workspace_bytes(int batch, int h, int w) {
+    if (batch <= 0 || h <= 0 || w <= 0) return 0;
+    const long rows = (long)batch * h;
+    const long blocks = rows < 2048 ? rows : 2048;
+    return (size_t)blocks * 1154 * sizeof(float);
+}
+/* decoder[36:38] backward: dy (B,2,h,w) planes; x (B,h,w,64) the layer's input; dxp (B,h+2,w+2,64) the data gradient on the padded
+ * domain (fold with holo_fold_reflect_f32, border 1), dw (2,64,3,3), db (2).  dxp / dw+db may be NULL to skip either part. */
+int holo_conv_last_bwd_f32(const float* dy, const float* x_nhwc, const float* w_oihw, float* dxp, float* dw, float* db, int batch, int h,
+                           int w, void* workspace, size_t workspace_bytes, void* stream) {
+    HOLO_REQUIRE(dy && w_oihw, HOLO_ERR_ARG, "holo_conv_last_bwd_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG, "holo_conv_last_bwd_f32: batch=%d h=%d w=%d", batch, h, w);
+    if (dxp) {
+        const long total = (long)batch * (h + 2) * (w + 2) * 16;
+        hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dy, w_oihw, dxp, h, w, total);
+    }
+    if (dw) {
+        HOLO_REQUIRE(db && x_nhwc && workspace, HOLO_ERR_ARG, "holo_conv_last_bwd_f32: weight gradient needs x, db and a workspace");
+        HOLO_REQUIRE(workspace_bytes >= holo_conv_last_bwd_workspace_bytes(batch, h, w), HOLO_ERR_WORKSPACE, "holo_conv_last_bwd_f32: workspace too small");
+        const long rows = (long)batch * h;
+        const int blocks = (int)(rows < 2048 ? rows : 2048);
+        const int rpb = (int)((rows + blocks - 1) / blocks);
+        const int nb = (int)((rows + rpb - 1) / rpb);
+        hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(nb), dim3(384), 0, as_stream(stream), x_nhwc, dy, static_cast<float*>(workspace), batch, h, w, rpb);
+        hipLaunchKernelGGL(conv_last_wgrad_final_kernel, dim3(5), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), dw, db, nb);
+    }
+    return check_launch("holo_conv_last_bwd_f32");
+}
+
+/* vgg[0:4] backward, data gradient only (the encoder is frozen, net.py:167-170): da (B,h,w,64) = gradient of the ReLU'd output
+ * already masked; din (B,1,h,w); workspace (B,h+2,w+2,4) floats */
+int holo_conv_first_dgrad_f32(const float* da, const float* w0, const float* w1, float* din, int batch, int h, int w, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    HOLO_REQUIRE(da && w0 && w1 && din && workspace, HOLO_ERR_ARG, "holo_conv_first_dgrad_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG, "holo_conv_first_dgrad_f32: batch=%d h=%d w=%d", batch, h, w);
+    HOLO_REQUIRE(workspace_bytes >= (size_t)batch * (h + 2) * (w + 2) * 4 * sizeof(float), HOLO_ERR_WORKSPACE, "holo_conv_first_dgrad_f32: workspace too small");
+    const long tp = (long)batch * (h + 2) * (w + 2);
+    hipLaunchKernelGGL(conv_first_dgrad_pad_kernel, dim3(blocks_for(tp)), dim3(256), 0, as_stream(stream), da, w1, static_cast<float*>(workspace), h, w, tp);
+    const long t = (long)batch * h * w;
+    hipLaunchKernelGGL(conv_first_dgrad_fold_kernel, dim3(blocks_for(t)), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), w0, din, h, w, t);
+    return check_launch("holo_conv_first_dgrad_f32");
+}
+
+int holo_mean_std_bwd_f32(const float* x_nhwc, const float* mean, const float* stdv, const float* dmean, const float* dstd, float* dx,
+                          int batch, int hw, int c, void* stream) {
+    HOLO_REQUIRE(x_nhwc && mean && stdv && dmean && dstd && dx, HOLO_ERR_ARG, "holo_mean_std_bwd_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && hw > 1 && c > 0 && c % 4 == 0, HOLO_ERR_ARG, "holo_mean_std_bwd_f32: batch=%d hw=%d c=%d", batch, hw, c);
+    const long total = (long)batch * hw * (c / 4);
+    hipLaunchKernelGGL(mean_std_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x_nhwc, mean, stdv, dmean, dstd, dx, hw, c / 4, total);
+    return check_launch("holo_mean_std_bwd_f32");
+}
+
+/* Linear backward: dx (B,fin) (or NULL), dw (fout,fin) + db (fout) (or NULL) */
+int holo_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int batch, int fin, int fout, void* stream) {
+    HOLO_REQUIRE(dy && (dx || dw), HOLO_ERR_ARG, "holo_linear_bwd_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && fin > 0 && fout > 0, HOLO_ERR_ARG, "holo_linear_bwd_f32: batch=%d fin=%d fout=%d", batch, fin, fout);
+    if (dx) {
+        HOLO_REQUIRE(w, HOLO_ERR_ARG, "holo_linear_bwd_f32: dx needs w");
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(blocks_for((long)batch * fin)), dim3(256), 0, as_stream(stream), dy, w, dx, batch, fin, fout);
+    }
+    if (dw) {
+        HOLO_REQUIRE(x && db, HOLO_ERR_ARG, "holo_linear_bwd_f32: dw needs x and db");
+        hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(blocks_for((long)fout * fin)), dim3(256), 0, as_stream(stream), dy, x, dw, db, batch, fin, fout);
+    }
+    return check_launch("holo_linear_bwd_f32");
+}
+int holo_rownorm_relu_bwd_f32(const float* z, const float* dy, float* dz, int batch, int f, float eps, void* stream) {
+    HOLO_REQUIRE(z && dy && dz, HOLO_ERR_ARG, "holo_rownorm_relu_bwd_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && f > 0, HOLO_ERR_ARG, "holo_rownorm_relu_bwd_f32: batch=%d f=%d", batch, f);
+    hipLaunchKernelGGL(rownorm_relu_bwd_kernel, dim3(batch), dim3(256), 0, as_stream(stream), z, dy, dz, f, eps);
+    return check_launch("holo_rownorm_relu_bwd_f32");
+}
+int holo_sigmoid_bwd_f32(const float* y, const float* dy, float* dz, int n, void* stream) {
+    HOLO_REQUIRE(y && dy && dz && n > 0, HOLO_ERR_ARG, "holo_sigmoid_bwd_f32: bad argument");
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), y, dy, dz, n);
+    return check_launch("holo_sigmoid_bwd_f32");
+}
+
+}  // extern "C"

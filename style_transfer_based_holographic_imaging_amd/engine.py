@@ -215,7 +215,17 @@ class Plan:
 
     def run(self, x):
         """x: logical (B,C,H,W) for a plan that starts with conv_first, else NHWC (B,H,W,C).
-        Returns NHWC, or NCHW (B,2,H,W) planes when the plan ends with conv_last."""
+        Returns NHWC, or NCHW (B,2,H,W) planes when the plan ends with conv_last.
+        While autograd is recording and the input or a parameter of the plan asks for a gradient, every step runs through its
+        ``autograd`` Function (fp32 only): the backward pass of the training objective."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for st in self.steps for m in (st.conv, st.conv0)
+                                                                if m is not None for p in m.parameters())):
+            if self.dtype != torch.float32:
+                raise NotImplementedError("the backward pass exists in fp32 only: set_compute_dtype(torch.float32) for training")
+            from . import autograd as _ag
+            for st in self.steps:
+                x = _ag.run_step(st, x)
+            return x
         for idx in range(len(self.steps)):
             x = self.run_step(idx, x)
         return x

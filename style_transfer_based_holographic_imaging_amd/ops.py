@@ -559,3 +559,167 @@ def unwrap2d(phase: torch.Tensor) -> torch.Tensor:
             x.data_ptr() + i0 * st * 4, st, out.data_ptr() + i0 * h * w * 4, h * w, nb, h, w,
             ws.data_ptr(), ws_bytes, _stream()), nbytes=8.0 * h * w * nb, fresh=True)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# backward pass (include/holo_hip.h ABI 5, csrc/backward.hip; SURVEY.md 8f N4: net.py:199-226)
+# ---------------------------------------------------------------------------------------------
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+def maxpool2x2(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """MaxPool2d(2,2,ceil_mode=True) on NHWC fp32, unfused (training keeps the pre-pool activation)."""
+    _req(x_nhwc)
+    x_nhwc = _f32c(x_nhwc)
+    b, h, w, c = x_nhwc.shape
+    y = torch.empty((b, (h + 1) // 2, (w + 1) // 2, c), dtype=torch.float32, device=x_nhwc.device)
+    _launch("holo_maxpool2x2_f32", lambda: lib.holo_maxpool2x2_f32(x_nhwc.data_ptr(), y.data_ptr(), b, h, w, c, _stream()),
+            nbytes=5.0 * b * h * w * c)
+    return y
+
+
+def relu_pool_bwd_pad(dy, y_act, y_pool, relu: bool, border: int) -> torch.Tensor:
+    """Gradient of a conv step's pre-activation embedded in a zero border: dy routed through the (optional) max-pool and masked
+    by the (optional) ReLU.  y_act: (B,h,w,c) post-ReLU pre-pool output; dy, y_pool: pooled shape when y_pool is given."""
+    _req(dy, y_act)
+    dy, y_act = _f32c(dy), _f32c(y_act)
+    b, h, w, c = y_act.shape
+    yp = _f32c(y_pool) if y_pool is not None else None
+    out = torch.empty((b, h + 2 * border, w + 2 * border, c), dtype=torch.float32, device=dy.device)
+    _launch("holo_relu_pool_bwd_pad_f32",
+            lambda: lib.holo_relu_pool_bwd_pad_f32(dy.data_ptr(), y_act.data_ptr(), yp.data_ptr() if yp is not None else 0, out.data_ptr(),
+                                                   b, h, w, c, int(bool(relu)), int(border), _stream()),
+            nbytes=12.0 * b * h * w * c)
+    return out
+
+
+def fold_reflect(dxp, h: int, w: int, border: int) -> torch.Tensor:
+    """Adjoint of ReflectionPad2d(1): (B,h+2*border,w+2*border,c) -> (B,h,w,c)."""
+    _req(dxp)
+    dxp = _f32c(dxp)
+    b, hp, wp, c = dxp.shape
+    assert hp == h + 2 * border and wp == w + 2 * border
+    dx = torch.empty((b, h, w, c), dtype=torch.float32, device=dxp.device)
+    _launch("holo_fold_reflect_f32", lambda: lib.holo_fold_reflect_f32(dxp.data_ptr(), dx.data_ptr(), b, h, w, c, int(border), _stream()),
+            nbytes=8.0 * b * h * w * c)
+    return dx
+
+
+def space_to_depth2_relu(dy, y, relu: bool) -> torch.Tensor:
+    """(B,2h,2w,c) gradient of a transposed-conv step's output -> (B,h,w,4c), masked by its ReLU."""
+    _req(dy)
+    dy = _f32c(dy)
+    b, h2, w2, c = dy.shape
+    yy = _f32c(y) if relu else None
+    g = torch.empty((b, h2 // 2, w2 // 2, 4 * c), dtype=torch.float32, device=dy.device)
+    _launch("holo_space_to_depth2_relu_f32",
+            lambda: lib.holo_space_to_depth2_relu_f32(dy.data_ptr(), yy.data_ptr() if yy is not None else 0, g.data_ptr(), b, h2 // 2, w2 // 2, c,
+                                                      int(bool(relu)), _stream()), nbytes=12.0 * dy.numel())
+    return g
+
+
+def channel_sum(x_rows_c: torch.Tensor) -> torch.Tensor:
+    """sum over all leading dimensions of a (..., c) fp32 tensor (bias gradients); c % 64 == 0"""
+    _req(x_rows_c)
+    x_rows_c = _f32c(x_rows_c)
+    c = x_rows_c.shape[-1]
+    rows = x_rows_c.numel() // c
+    out = torch.empty((c,), dtype=torch.float32, device=x_rows_c.device)
+    n = lib.holo_channel_sum_workspace_bytes(rows, c)
+    ws = _ws(n, x_rows_c.device)
+    _launch("holo_channel_sum_f32", lambda: lib.holo_channel_sum_f32(x_rows_c.data_ptr(), out.data_ptr(), rows, c, ws.data_ptr(), n, _stream()),
+            nbytes=4.0 * x_rows_c.numel())
+    return out
+
+
+def pix_gemm(p_padded, p_border: int, q, taps: int) -> torch.Tensor:
+    """out[m][n][tap] = sum over pixels P[pixel][m] * Q[reflect(pixel + tap)][n] (weight gradients; fp32 MFMA, deterministic)."""
+    _req(p_padded, q)
+    p_padded, q = _f32c(p_padded), _f32c(q)
+    b, h, w, nc = q.shape
+    mc = p_padded.shape[-1]
+    assert p_padded.shape[1] == h + 2 * p_border and p_padded.shape[2] == w + 2 * p_border
+    out = torch.empty((mc, nc, taps), dtype=torch.float32, device=q.device)
+    n = lib.holo_pix_gemm_workspace_bytes(b, h, w, mc, nc, taps)
+    ws = _ws(n, q.device)
+    _launch("holo_pix_gemm_f32", lambda: lib.holo_pix_gemm_f32(p_padded.data_ptr(), int(p_border), q.data_ptr(), out.data_ptr(), b, h, w, mc, nc,
+                                                               int(taps), ws.data_ptr(), n, _stream()),
+            flops=2.0 * taps * mc * nc * b * h * w, nbytes=4.0 * (p_padded.numel() + q.numel()))
+    return out
+
+
+def conv_last_bwd(dy_planes, x_nhwc, w_oihw, need_dx=True, need_dw=True):
+    """decoder[36:38] backward: returns (dx (B,h,w,64) or None, dw (2,64,3,3) or None, db (2) or None)."""
+    _req(dy_planes, x_nhwc, w_oihw)
+    dy_planes, x_nhwc, w_oihw = _f32c(dy_planes), _f32c(x_nhwc), _f32c(w_oihw.detach())
+    b, h, w, _ = x_nhwc.shape
+    dev = x_nhwc.device
+    dxp = torch.empty((b, h + 2, w + 2, 64), dtype=torch.float32, device=dev) if need_dx else None
+    dw = torch.empty((2, 64, 3, 3), dtype=torch.float32, device=dev) if need_dw else None
+    db = torch.empty((2,), dtype=torch.float32, device=dev) if need_dw else None
+    n = lib.holo_conv_last_bwd_workspace_bytes(b, h, w)
+    ws = _ws(n, dev)
+    _launch("holo_conv_last_bwd_f32",
+            lambda: lib.holo_conv_last_bwd_f32(dy_planes.data_ptr(), x_nhwc.data_ptr(), w_oihw.data_ptr(), dxp.data_ptr() if need_dx else 0,
+                                               dw.data_ptr() if need_dw else 0, db.data_ptr() if need_dw else 0, b, h, w, ws.data_ptr(), n, _stream()),
+            flops=2.0 * 2 * 64 * 9 * b * h * w * (int(need_dx) + int(need_dw)), nbytes=4.0 * x_nhwc.numel())
+    dx = fold_reflect(dxp, h, w, 1) if need_dx else None
+    return dx, dw, db
+
+
+def conv_first_dgrad(da_nhwc, w0, w1) -> torch.Tensor:
+    """vgg[0:4] backward, data gradient: (B,h,w,64) masked gradient -> (B,1,h,w)."""
+    _req(da_nhwc, w0, w1)
+    da_nhwc = _f32c(da_nhwc)
+    b, h, w, _ = da_nhwc.shape
+    din = torch.empty((b, 1, h, w), dtype=torch.float32, device=da_nhwc.device)
+    n = b * (h + 2) * (w + 2) * 16
+    ws = _ws(n, da_nhwc.device)
+    w0c, w1c = _f32c(w0.detach()), _f32c(w1.detach())
+    _launch("holo_conv_first_dgrad_f32", lambda: lib.holo_conv_first_dgrad_f32(da_nhwc.data_ptr(), w0c.data_ptr(), w1c.data_ptr(), din.data_ptr(),
+                                                                               b, h, w, ws.data_ptr(), n, _stream()),
+            flops=2.0 * 27 * 64 * b * h * w, nbytes=4.0 * da_nhwc.numel())
+    return din
+
+
+def mean_std_bwd(x_nhwc, mean, std, dmean, dstd) -> torch.Tensor:
+    """calc_mean_std backward on NHWC fp32: mean/std/dmean/dstd (B,C)."""
+    _req(x_nhwc, mean, std, dmean, dstd)
+    x_nhwc = _f32c(x_nhwc)
+    b, h, w, c = x_nhwc.shape
+    m, s, dm, ds = (_f32c(t.reshape(b, c)) for t in (mean, std, dmean, dstd))
+    dx = torch.empty_like(x_nhwc)
+    _launch("holo_mean_std_bwd_f32", lambda: lib.holo_mean_std_bwd_f32(x_nhwc.data_ptr(), m.data_ptr(), s.data_ptr(), dm.data_ptr(), ds.data_ptr(),
+                                                                       dx.data_ptr(), b, h * w, c, _stream()), nbytes=8.0 * x_nhwc.numel())
+    return dx
+
+
+def linear_bwd(dy, x, w, need_dx=True, need_dw=True):
+    _req(dy, x, w)
+    dy, x, w = _f32c(dy), _f32c(x), _f32c(w.detach())
+    b, fout = dy.shape
+    fin = x.shape[1]
+    dx = torch.empty((b, fin), dtype=torch.float32, device=dy.device) if need_dx else None
+    dw = torch.empty((fout, fin), dtype=torch.float32, device=dy.device) if need_dw else None
+    db = torch.empty((fout,), dtype=torch.float32, device=dy.device) if need_dw else None
+    _launch("holo_linear_bwd_f32", lambda: lib.holo_linear_bwd_f32(dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr() if need_dx else 0,
+                                                                   dw.data_ptr() if need_dw else 0, db.data_ptr() if need_dw else 0, b, fin, fout, _stream()))
+    return dx, dw, db
+
+
+def rownorm_relu_bwd(z, dy, eps=1e-5) -> torch.Tensor:
+    _req(z, dy)
+    z, dy = _f32c(z), _f32c(dy)
+    b, f = z.shape
+    dz = torch.empty_like(z)
+    _launch("holo_rownorm_relu_bwd_f32", lambda: lib.holo_rownorm_relu_bwd_f32(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), b, f, float(eps), _stream()))
+    return dz
+
+
+def sigmoid_bwd(y, dy) -> torch.Tensor:
+    _req(y, dy)
+    y, dy = _f32c(y), _f32c(dy)
+    dz = torch.empty_like(y)
+    _launch("holo_sigmoid_bwd_f32", lambda: lib.holo_sigmoid_bwd_f32(y.data_ptr(), dy.data_ptr(), dz.data_ptr(), y.numel(), _stream()))
+    return dz

@@ -18,6 +18,8 @@ Outputs (float32 unless noted, all small):
   golden_edges.npz       B=1, multi-style, alpha 0/0.5, odd size 36, other style vectors
   golden_asm.npz         ASM / Holo_Generator modes on seeded fields (incl. zero_padding=False)
   golden_forward.npz     Net.forward (the training objective's forward values: losses, g_t, style reconstruction, distances)
+  golden_backward.npz    gradients of a scalar objective built from all seven results of Net.forward (torch.autograd on the
+                         reference): per parameter of the decoder and the distance head its sum, L2 norm and 256 fixed samples
 """
 import argparse
 import os
@@ -237,6 +239,33 @@ def main():
         fwd.update(plain_loss_c=lc2, plain_loss_s=ls2, five_style_re=five[4], style_img=style_img, content=content)
     np.savez_compressed(os.path.join(args.out, "golden_forward.npz"),
                         **{k: v.contiguous().numpy() for k, v in fwd.items()}, seed=args.seed)
+
+    # ---- 6. Net.forward backward: the reference's own gradients (torch.autograd over its aten graph) ------------
+    # objective = loss_c + 10 loss_s + <g_t, u1> + <g_t_phase, u2> + <style_re, u3> + <d_content, u4> + <d_style, u5> with fixed
+    # cosine patterns u (no RNG): every output of the method feeds the gradient.  alpha 0.6 exercises the blend.
+    def pattern(t, k):
+        idx = torch.arange(t.numel(), dtype=torch.float64).view(t.shape)
+        return torch.cos(idx * (0.37 + 0.11 * k) + k).float()
+
+    for p in network.decoder.parameters():
+        p.requires_grad_(True)
+    for p in network.distance_g.parameters():
+        p.requires_grad_(True)
+    network.zero_grad()
+    lc, ls, g_t, g_ph, s_re, d_c_pred, d_s_pred = network(content, style_img, 0.6, True, True)
+    objective = (lc + 10.0 * ls + (g_t * pattern(g_t, 1)).mean() + (g_ph * pattern(g_ph, 2)).mean() + (s_re * pattern(s_re, 3)).mean()
+                 + (d_c_pred * pattern(d_c_pred, 4)).sum() + (d_s_pred * pattern(d_s_pred, 5)).sum())
+    objective.backward()
+    bwd = {"objective": objective.detach()}
+    for prefix, module in (("decoder", network.decoder), ("distance_g", network.distance_g)):
+        for name, p in module.named_parameters():
+            gflat = p.grad.detach().reshape(-1)
+            pick = torch.linspace(0, gflat.numel() - 1, min(256, gflat.numel())).round().long()
+            bwd[f"{prefix}.{name}.sum"] = gflat.double().sum().float()
+            bwd[f"{prefix}.{name}.norm"] = gflat.double().norm().float()
+            bwd[f"{prefix}.{name}.samples"] = gflat[pick].clone()
+    np.savez_compressed(os.path.join(args.out, "golden_backward.npz"),
+                        **{k: v.contiguous().numpy() for k, v in bwd.items()}, seed=args.seed)
 
     for f in sorted(os.listdir(args.out)):
         if f.endswith(".npz"):

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/holo_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), "ctypes SIGNATURES and the header disagree"
-    assert _lib.lib.holo_abi_version() == 4
+    assert _lib.lib.holo_abi_version() == 5
     assert _lib.lib.holo_target_arch() == b"gfx950"
 
 

@@ -17,6 +17,9 @@
 //   * the skinny layers (3 -> 64 first, 64 -> 2 last), statistics and the distance head: small VALU kernels.
 //
 // Everything is exact fp32 arithmetic; results differ from torch.autograd by summation order only (tests/test_hip_backward.py).
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace holo {
@@ -186,51 +189,93 @@ __global__ __launch_bounds__(256) void channel_sum_final_kernel(const double* __
 // P: (B, h + 2*pb, w + 2*pb, mc) (the embedded gradient; interior read), Q: (B, h, w, nc).  Block = 4 waves on one 32 x 32 (m, n)
 // tile; blockIdx.z and the wave index split the image rows; every (split, wave) writes its own partial tile, pix_gemm_reduce adds
 // them in order.  v_mfma_f32_32x32x2_f32: A lane (m = lane & 31, k = lane >> 5), B lane (k, n): k = two neighbouring pixels.
-template <int TAPS>
+// NT = 32-wide n tiles per wave (one tap: 4, so that one P value feeds four MFMAs).  The (row, pixel pair) steps of a wave form
+// one flat sequence; the operands of step s + 2 are in flight while step s multiplies (three register sets in rotation).
+template <int TAPS, int NT>
+struct PixFrag {
+    float a;
+    bool ok;          // false: the P value counts as zero (odd width's last pair, steps past the end); applied at the multiply
+    float b[TAPS * NT];
+};
+template <int TAPS, int NT>
 __global__ __launch_bounds__(256, 2) void pix_gemm_kernel(const float* __restrict__ p, int pb, const float* __restrict__ q,
                                                           float* __restrict__ part, int batch, int h, int w, int mc, int nc,
                                                           int rows_per_wave) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NB = TAPS * NT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hs = lane >> 5;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32 * NT;
     const long slot = (long)blockIdx.z * 4 + wave;                    // partial index
     const long row0 = slot * rows_per_wave;                           // image rows (n * h + y) of this wave
     const long rows_total = (long)batch * h;
     long row1 = row0 + rows_per_wave;
     if (row1 > rows_total) row1 = rows_total;
-    floatx16 acc[TAPS];
+    floatx16 acc[NB];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < NB; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     const int hp = h + 2 * pb, wp = w + 2 * pb;
-    for (long row = row0; row < row1; ++row) {
-        const long n = row / h;
-        const int y = (int)(row % h);
-        const float* __restrict__ prow = p + ((n * hp + y + pb) * (long)wp + pb) * mc + m0 + r;
-        const float* qrow[3];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int ry = TAPS == 9 ? reflect1(y + dy - 1, h) : y;
-            qrow[dy] = q + (n * h + ry) * (long)w * nc + n0 + r;
-        }
-        for (int x = 0; x < w; x += 2) {
-            const int xx = x + hs;
-            const bool ok = xx < w;
-            const float a = ok ? prow[(long)xx * mc] : 0.0f;
+    const int xsteps = (w + 1) >> 1;
+    const int steps = row1 > row0 ? (int)(row1 - row0) * xsteps : 0;
+    if (steps > 0) {
+        // load cursor (wave-uniform): image cn, row cy, pixel pair cx.  The loop body is branch-free so that the operands of two
+        // later steps stay in flight behind counted waits: past the last step the cursor stays put and the P value reads as zero.
+        int cn = (int)(row0 / h), cy = (int)(row0 - (long)cn * h), cx = 0;
+        auto issue = [&](PixFrag<TAPS, NT>& f, int idx) {
+            const int xx = cx + hs;
+            const bool ok = xx < w && idx < steps;
+            const int xc = xx < w ? xx : w - 1;
+            const float av = p[(((long)cn * hp + cy + pb) * wp + pb + xc) * mc + m0 + r];
+            f.a = av;
+            f.ok = ok;
             if constexpr (TAPS == 9) {
+                long qoff[3];
                 int rx[3];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) rx[dx] = reflect1(xx + dx - 1, w);
-                float b[9];
+                for (int d = 0; d < 3; ++d) {
+                    qoff[d] = ((long)cn * h + reflect1(cy + d - 1, h)) * w;
+                    rx[d] = reflect1(xc + d - 1, w);
+                }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) b[t] = qrow[t / 3][(long)rx[t % 3] * nc];
+                for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) f.b[t * NT + j] = q[(qoff[t / 3] + rx[t % 3]) * nc + n0 + r + 32 * j];
             } else {
-                const float b = qrow[0][(long)(ok ? xx : 0) * nc];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+                const long qoff = (((long)cn * h + cy) * w + xc) * nc + n0 + r;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) f.b[j] = q[qoff + 32 * j];
             }
+            const bool adv = idx + 1 < steps;
+            const int nx = cx + 2;
+            const bool wrap_x = nx >= w;
+            const int ny = cy + (wrap_x ? 1 : 0);
+            const bool wrap_y = ny >= h;
+            cx = adv ? (wrap_x ? 0 : nx) : cx;
+            cy = adv ? (wrap_y ? 0 : ny) : cy;
+            cn = adv ? cn + (wrap_y ? 1 : 0) : cn;
+        };
+        auto multiply = [&](const PixFrag<TAPS, NT>& f) {
+            const float a = f.ok ? f.a : 0.0f;
+#pragma unroll
+            for (int t = 0; t < NB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.b[t], acc[t], 0, 0, 0);
+        };
+        PixFrag<TAPS, NT> f0, f1, f2;
+        issue(f0, 0);
+        issue(f1, 1);
+        for (int s = 0; s < steps; s += 3) {         // the fences keep the compiler from sinking a set's loads below its use
+            issue(f2, s + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(f0, s + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(f1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(f1, s + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(f2);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // D[m][n]: m = (i & 3) + 8 * (i >> 2) + 4 * hs, n = r.  Partial layout [slot][m][n][tap] over the FULL (mc, nc) matrix.
@@ -238,17 +283,143 @@ __global__ __launch_bounds__(256, 2) void pix_gemm_kernel(const float* __restric
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = (i & 3) + 8 * (i >> 2) + 4 * hs;
+                dst[((long)(m0 + m) * nc + n0 + 32 * j + r) * TAPS + t] = acc[t * NT + j][i];
+            }
+}
+// ---- the 9-tap case with both operands staged through LDS (w % 32 == 0, channels % 64 == 0) ------------------------------------
+// Block = 4 waves on a 64 x 64 (m, n) tile, wave (wm, wn) on 32 x 32 with its nine tap accumulators.  A block walks down the
+// rows [y0, y1) of one 32-pixel column strip of one image: per row it holds the strip of P (32 pixels x 64 channels, two buffers)
+// and a ring of four Q rows (the strip plus its reflected neighbours, 36 pixels x 64 channels), all filled by LDS-DMA one row
+// ahead of the multiplies, so every global byte is read by wide coalesced pieces and each Q row is fetched once for its three
+// vertical taps.  LDS image: [pixel][64 channels] linear with the two 32-channel halves of odd pixels exchanged (applied to the
+// per-lane SOURCE address of the DMA), so that the MFMA operand read - lanes 0..31 pixel X, lanes 32..63 pixel X + 1, 32 channels
+// each - hits 64 distinct banks.  One partial tile per block, tap-major ([unit][tap][m][n]); pix_gemm_reduce adds them in order.
+constexpr int kPgChunk = 32;
+constexpr int kPgHalo = 36;
+constexpr int kPgPBytes = kPgChunk * 64 * 4;
+constexpr int kPgQBytes = kPgHalo * 64 * 4;
+constexpr int kPgLdsBytes = 2 * kPgPBytes + 4 * kPgQBytes;
+
+__global__ __launch_bounds__(256, 2) void pix_gemm9_lds_kernel(const float* __restrict__ p, int pb, const float* __restrict__ q,
+                                                               float* __restrict__ part, int h, int w, int mc, int nc,
+                                                               int rows_per_unit, int groups) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kPgLdsBytes];
+    const float* sf = reinterpret_cast<const float*>(smem);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hs = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int chunks = w / kPgChunk;
+    int u = blockIdx.z;
+    const int g = u % groups;
+    u /= groups;
+    const int c = u % chunks, n = u / chunks;
+    const int y0 = g * rows_per_unit;
+    int y1 = y0 + rows_per_unit;
+    if (y1 > h) y1 = h;
+    const int cx0 = c * kPgChunk;
+    const int hp = h + 2 * pb, wp = w + 2 * pb;
+    const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
+
+#define PG_GLDS(sbase_, voff_, ldst_)                                                                      \
+    {                                                                                                      \
+        unsigned m0_keep;                                                                                  \
+        const unsigned lds_u = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(ldst_));               \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t" \
+                     "s_mov_b32 m0, %0"                                                                     \
+                     : "=&s"(m0_keep)                                                                      \
+                     : "v"(voff_), "s"(sbase_), "s"(lds_u)                                                 \
+                     : "memory");                                                                          \
+    }
+    // a DMA piece = 4 pixels x 64 channels (1 KiB): lane -> pixel lane >> 4 of the piece, 4 channels from (lane & 15) * 4
+    const int lpx = lane >> 4, lch = (lane & 15) * 4;
+    auto fill_p = [&](int y, int buf) {               // 8 pieces, two per wave
+        const float* rowp = p + (((long)n * hp + y + pb) * wp + pb + cx0) * mc + m0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = wave + 4 * k;
+            const unsigned off = (unsigned)(((4 * j + lpx) * mc + (lch ^ (32 * (lpx & 1)))) * 4);
+            PG_GLDS(rowp, off, buf * kPgPBytes + j * 1024);
+        }
+    };
+    auto fill_q = [&](int ry, int slot) {             // 9 pieces: wave 0 takes three
+        const float* rowq = q + ((long)n * h + ry) * w * nc + n0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = wave + 4 * k;
+            if (j < 9) {
+                const int x = reflect1(cx0 - 1 + 4 * j + lpx, w);
+                const unsigned off = (unsigned)((x * nc + (lch ^ (32 * (lpx & 1)))) * 4);
+                PG_GLDS(rowq, off, 2 * kPgPBytes + slot * kPgQBytes + j * 1024);
+            }
+        }
+    };
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    // operand read positions (float index): pixel hs of a pair, channel half swapped for odd pixels
+    const int pa_lane = hs * 64 + ((wm * 32 + r) ^ (32 * hs));
+    int qb_lane[2];
+    qb_lane[0] = hs * 64 + ((wn * 32 + r) ^ (32 * hs)) + 2 * kPgPBytes / 4;              // even tap column: pixel parity = hs
+    qb_lane[1] = hs * 64 + ((wn * 32 + r) ^ (32 * (hs ^ 1))) + 2 * kPgPBytes / 4;        // odd tap column
+
+    fill_p(y0, y0 & 1);
+    if (y0 > 0) fill_q(y0 - 1, (y0 - 1) & 3);
+    fill_q(y0, y0 & 3);
+    if (y0 + 1 < h) fill_q(y0 + 1, (y0 + 1) & 3);
+    for (int y = y0; y < y1; ++y) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // row y landed for every wave; every wave is done reading row y - 1
+        if (y + 1 < y1) {
+            fill_p(y + 1, (y + 1) & 1);
+            if (y + 2 < h) fill_q(y + 2, (y + 2) & 3);
+        }
+        const int pa = pa_lane + (y & 1) * (kPgPBytes / 4);
+        int qrow[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) qrow[d] = (reflect1(y + d - 1, h) & 3) * (kPgQBytes / 4);
+#pragma unroll
+        for (int s2 = 0; s2 < kPgChunk / 2; ++s2) {
+            const float a = sf[pa + s2 * 128];
+            float b[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b[t] = sf[qrow[t / 3] + qb_lane[(t % 3) & 1] + (2 * s2 + t % 3) * 64];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+        }
+    }
+#undef PG_GLDS
+    // D[m][n]: m = (i & 3) + 8 * (i >> 2) + 4 * hs, n = r
+    float* __restrict__ dst = part + (long)blockIdx.z * mc * nc * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = (i & 3) + 8 * (i >> 2) + 4 * hs;
-            dst[((long)(m0 + m) * nc + n0 + r) * TAPS + t] = acc[t][i];
+            dst[((long)t * mc + m0 + wm * 32 + m) * nc + n0 + wn * 32 + r] = acc[t][i];
         }
 }
-__global__ __launch_bounds__(256) void pix_gemm_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long elems, int slots) {
+
+// out[m][n][tap] = sum over the partial tiles, in slot order.  tap_major: partials laid out [slot][tap][m][n], else [slot][m][n][tap]
+__global__ __launch_bounds__(256) void pix_gemm_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long elems, int slots,
+                                                              int taps, int tap_major) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= elems) return;
     float s = 0.0f;
     for (int k = 0; k < slots; ++k) s += part[(long)k * elems + i];
-    out[i] = s;
+    if (tap_major) {
+        const long mn = elems / taps;
+        out[(i % mn) * taps + i / mn] = s;
+    } else {
+        out[i] = s;
+    }
 }
 
 // ---- last layer (ReflPad + Conv2d(64, 2, 3x3), no activation; NHWC in, NCHW planes out), backward ------------------------------
@@ -495,9 +666,33 @@ struct PixGemmPlan {
     int rows_per_wave, splits;
     long slots;
 };
-static PixGemmPlan pix_gemm_plan(int batch, int h, int mc, int nc) {
+static inline int pix_gemm_nt(int nc, int taps) { return taps == 1 && nc % 128 == 0 ? 4 : 1; }
+// HOLO_PIX_GEMM_DIRECT=1: the operands-from-global kernel for every shape (A/B timing, tests of both kernels on one shape)
+static inline bool pix_gemm_force_direct() {
+    const char* e = getenv("HOLO_PIX_GEMM_DIRECT");
+    return e && e[0] == '1';
+}
+static inline bool pix_gemm_lds(int w, int mc, int nc, int taps) { return taps == 9 && w % kPgChunk == 0 && mc % 64 == 0 && nc % 64 == 0; }
+// the LDS-staged kernel's units: (image, 32-pixel strip, row group); about four blocks per CU over the grid
+struct PixGemmLdsPlan {
+    int rows_per_unit, groups;
+    long units;
+};
+static PixGemmLdsPlan pix_gemm_lds_plan(int batch, int h, int w, int mc, int nc) {
+    const long tiles = (long)(mc / 64) * (nc / 64);
+    const long strips = (long)batch * (w / kPgChunk);
+    long groups = (1024 + tiles * strips - 1) / (tiles * strips);
+    if (groups > h / 2) groups = h / 2;
+    if (groups < 1) groups = 1;
+    PixGemmLdsPlan pl;
+    pl.rows_per_unit = (int)((h + groups - 1) / groups);
+    pl.groups = (h + pl.rows_per_unit - 1) / pl.rows_per_unit;
+    pl.units = strips * pl.groups;
+    return pl;
+}
+static PixGemmPlan pix_gemm_plan(int batch, int h, int mc, int nc, int nt) {
     const long rows = (long)batch * h;
-    const long tiles = (long)(mc / 32) * (nc / 32);
+    const long tiles = (long)(mc / 32) * (nc / (32 * nt));
     // aim at ~8 blocks per CU over the whole grid, at least 2 image rows per wave
     long splits = (2048 + tiles - 1) / tiles;
     if (splits < 1) splits = 1;
@@ -571,8 +766,10 @@ int holo_channel_sum_f32(const float* x, float* out, long rows, int c, void* wor
 
 size_t holo_pix_gemm_workspace_bytes(int batch, int h, int w, int mc, int nc, int taps) {
     if (batch <= 0 || h <= 0 || w <= 0 || mc <= 0 || nc <= 0 || (taps != 1 && taps != 9)) return 0;
-    const PixGemmPlan p = pix_gemm_plan(batch, h, mc, nc);
-    return (size_t)p.slots * mc * nc * taps * sizeof(float);
+    const PixGemmPlan p = pix_gemm_plan(batch, h, mc, nc, pix_gemm_nt(nc, taps));
+    long slots = p.slots;                              // room for either kernel's partial tiles
+    if (pix_gemm_lds(w, mc, nc, taps)) slots = std::max(slots, pix_gemm_lds_plan(batch, h, w, mc, nc).units);
+    return (size_t)slots * mc * nc * taps * sizeof(float);
 }
 /* out[m][n][tap] = sum over the B*h*w pixels of P[pixel][m] * Q[reflect(pixel + tap)][n]; taps = 9 (3x3, tap = ky*3+kx, reflected
  * neighbour) or 1 (the pixel itself).  P: (B, h + 2*p_border, w + 2*p_border, mc) NHWC read at its interior, Q: (B, h, w, nc). */
@@ -582,15 +779,26 @@ int holo_pix_gemm_f32(const float* p, int p_border, const float* q, float* out, 
     HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && mc > 0 && nc > 0 && mc % 32 == 0 && nc % 32 == 0 && (taps == 1 || taps == 9) && p_border >= 0,
                  HOLO_ERR_ARG, "holo_pix_gemm_f32: batch=%d h=%d w=%d mc=%d nc=%d taps=%d (channels %% 32, taps 1 | 9)", batch, h, w, mc, nc, taps);
     HOLO_REQUIRE(workspace_bytes >= holo_pix_gemm_workspace_bytes(batch, h, w, mc, nc, taps), HOLO_ERR_WORKSPACE, "holo_pix_gemm_f32: workspace too small");
-    const PixGemmPlan pl = pix_gemm_plan(batch, h, mc, nc);
     float* part = static_cast<float*>(workspace);
-    const dim3 grid(mc / 32, nc / 32, pl.splits);
-    if (taps == 9)
-        hipLaunchKernelGGL(pix_gemm_kernel<9>, grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
-    else
-        hipLaunchKernelGGL(pix_gemm_kernel<1>, grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
     const long elems = (long)mc * nc * taps;
-    hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), part, out, elems, (int)pl.slots);
+    if (pix_gemm_lds(w, mc, nc, taps) && !pix_gemm_force_direct()) {
+        const PixGemmLdsPlan lp = pix_gemm_lds_plan(batch, h, w, mc, nc);
+        HOLO_REQUIRE(lp.units <= 65535, HOLO_ERR_ARG, "holo_pix_gemm_f32: %ld work units (grid limit 65535)", lp.units);
+        hipLaunchKernelGGL(pix_gemm9_lds_kernel, dim3(mc / 64, nc / 64, (unsigned)lp.units), dim3(256), 0, as_stream(stream), p, p_border, q, part,
+                           h, w, mc, nc, lp.rows_per_unit, lp.groups);
+        hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), part, out, elems, (int)lp.units, taps, 1);
+        return check_launch("holo_pix_gemm_f32");
+    }
+    const int nt = pix_gemm_nt(nc, taps);
+    const PixGemmPlan pl = pix_gemm_plan(batch, h, mc, nc, nt);
+    const dim3 grid(mc / 32, nc / (32 * nt), pl.splits);
+    if (taps == 9)
+        hipLaunchKernelGGL((pix_gemm_kernel<9, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
+    else if (nt == 4)
+        hipLaunchKernelGGL((pix_gemm_kernel<1, 4>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
+    else
+        hipLaunchKernelGGL((pix_gemm_kernel<1, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
+    hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), part, out, elems, (int)pl.slots, taps, 0);
     return check_launch("holo_pix_gemm_f32");
 }
 

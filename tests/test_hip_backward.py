@@ -31,6 +31,8 @@ def _nhwc(t, dev):
 @pytest.mark.parametrize("b,h,w,cin,cout,relu,pool", [
     (2, 12, 10, 64, 64, True, False), (1, 13, 9, 64, 128, True, True), (2, 8, 8, 128, 64, False, False),
     (1, 34, 18, 64, 64, True, True), (3, 5, 7, 256, 128, True, False), (1, 2, 2, 64, 64, True, True),
+    # widths of whole 32-pixel strips: the weight gradient runs on the LDS-staged kernel (one, two and three strips; row groups)
+    (2, 6, 32, 64, 64, True, False), (1, 9, 64, 128, 64, True, True), (1, 37, 96, 64, 128, False, False), (1, 2, 32, 64, 64, True, False),
 ])
 def test_conv_step(ag, dev, b, h, w, cin, cout, relu, pool):
     g = torch.Generator().manual_seed(h * 31 + cin)
@@ -52,6 +54,25 @@ def test_conv_step(ag, dev, b, h, w, cin, cout, relu, pool):
     assert rel_err(xd.grad.permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-5
     assert rel_err(wd.grad.cpu(), wr.grad) < 2e-5
     assert rel_err(bd.grad.cpu(), br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("b,h,w,mc,nc", [(2, 11, 32, 64, 64), (1, 40, 64, 128, 64), (3, 7, 32, 64, 192)])
+def test_pix_gemm_kernels_agree(dev, monkeypatch, b, h, w, mc, nc):
+    """the LDS-staged 9-tap kernel against the operands-from-global one (HOLO_PIX_GEMM_DIRECT=1) and a float64 einsum"""
+    from style_transfer_based_holographic_imaging_amd import ops
+    g = torch.Generator().manual_seed(w + mc + h)
+    pgrad = torch.randn(b, h + 4, w + 4, mc, generator=g).to(dev)
+    q = torch.randn(b, h, w, nc, generator=g).to(dev)
+    staged = ops.pix_gemm(pgrad, 2, q, 9)
+    monkeypatch.setenv("HOLO_PIX_GEMM_DIRECT", "1")
+    direct = ops.pix_gemm(pgrad, 2, q, 9)
+    monkeypatch.delenv("HOLO_PIX_GEMM_DIRECT")
+    qp = F.pad(q.permute(0, 3, 1, 2).double().cpu(), (1, 1, 1, 1), mode="reflect")
+    pi = pgrad[:, 2:-2, 2:-2, :].double().cpu()
+    want = torch.stack([torch.einsum("bhwm,bnhw->mn", pi, qp[:, :, t // 3:t // 3 + h, t % 3:t % 3 + w]) for t in range(9)], -1)
+    assert rel_err(staged.view(mc, nc, 9).cpu(), want) < 2e-6
+    assert rel_err(direct.view(mc, nc, 9).cpu(), want) < 2e-6
+    assert torch.equal(staged, ops.pix_gemm(pgrad, 2, q, 9))          # fixed summation order: run to run bit-identical
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,relu", [(2, 6, 5, 64, 64, True), (1, 7, 9, 128, 128, True), (1, 4, 4, 256, 256, False)])

@@ -295,6 +295,12 @@ int holo_conv_last_bwd_f32(const float* dy, const float* x_nhwc, const float* w_
  * of the ReLU'd output, din (B,1,h,w); workspace of B*(h+2)*(w+2)*4 floats */
 int holo_conv_first_dgrad_f32(const float* da, const float* w0, const float* w1, float* din, int batch, int h, int w,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* calc_mean_std (function.py:4-12) of an NHWC fp32 map with the pixels split over blocks: the large maps of the training losses
+ * (net.py:191-197) at small batch, where holo_channel_mean_std_f32's one block per (64 channels, image) leaves the chip idle.
+ * Same formulas; float64 partial sums of 1024 pixels added in part order.  c % 64 == 0, hw >= 2 */
+size_t holo_channel_mean_std_wide_workspace_bytes(int batch, int hw, int c);
+int holo_channel_mean_std_wide_f32(const float* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 /* calc_mean_std (function.py:4-12) backward: dx[p][c] = dmean[c]/HW + dstd[c]*(x[p][c]-mean[c])/((HW-1)*std[c]) */
 int holo_mean_std_bwd_f32(const float* x_nhwc, const float* mean, const float* stdv, const float* dmean, const float* dstd,
                           float* dx, int batch, int hw, int c, void* stream);

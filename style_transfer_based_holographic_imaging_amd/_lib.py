@@ -89,6 +89,8 @@ SIGNATURES = {
     "holo_conv_last_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "holo_conv_last_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "holo_conv_first_dgrad_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "holo_channel_mean_std_wide_workspace_bytes": (_z, [_i, _i, _i]),
+    "holo_channel_mean_std_wide_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _z, _p]),
     "holo_mean_std_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_linear_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_rownorm_relu_bwd_f32": (_i, [_p, _p, _p, _i, _i, _f, _p]),

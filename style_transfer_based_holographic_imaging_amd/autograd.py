@@ -139,8 +139,10 @@ class MeanStd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, eps):
-        mean, std = ops.channel_mean_std(x.detach(), eps)
-        ctx.save_for_backward(x.detach(), mean, std)
+        xd = x.detach()
+        wide = xd.dtype == torch.float32 and xd.shape[1] * xd.shape[2] > ops.WIDE_STATS_MIN_HW
+        mean, std = ops.channel_mean_std_wide(xd, eps) if wide else ops.channel_mean_std(xd, eps)
+        ctx.save_for_backward(xd, mean, std)
         return mean, std
 
     @staticmethod

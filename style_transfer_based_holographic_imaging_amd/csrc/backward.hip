@@ -154,6 +154,18 @@ __global__ __launch_bounds__(256) void space_to_depth2_relu_kernel(const float* 
     reinterpret_cast<float4*>(g)[i] = v;     // i = ((n*h + Y)*w + X)*4*c4 + q*c4 + cq
 }
 
+// ---- partial rows folded 32 to 1 (fixed order) until at most 64 remain: the finishing kernels below then walk a short list -----
+template <typename T>
+__global__ __launch_bounds__(256) void fold_rows_kernel(const T* __restrict__ in, T* __restrict__ out, long elems, int rows, int per) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    const int r0 = blockIdx.y * per;
+    const int r1 = r0 + per < rows ? r0 + per : rows;
+    T s = 0;
+    for (int r = r0; r < r1; ++r) s += in[(long)r * elems + i];
+    out[(long)blockIdx.y * elems + i] = s;
+}
+
 // ---- sum over pixels per channel (bias gradients): x (rows, c) -> out[c]; deterministic two-stage ------------------------------
 __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, double* __restrict__ part, long rows,
                                                                   int c, int parts) {
@@ -456,36 +468,43 @@ __global__ __launch_bounds__(256) void conv_last_dgrad_kernel(const float* __res
     }
     reinterpret_cast<float4*>(dxp)[i] = make_float4(s[0], s[1], s[2], s[3]);
 }
-// weight / bias gradient partials: block b takes a range of image rows; thread t < 1152 + 2 owns one (co, ci, tap) (or a bias)
-__global__ __launch_bounds__(384) void conv_last_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// weight / bias gradient partials: block b takes a range of image rows; thread = (tap row, input channel) with the three taps of
+// that row x both output channels in registers, the row of x sliding through a three-pixel window (one load per pixel).
+// Partial layout per block: [tap][co][ci] (1152) + 2 bias sums.
+__global__ __launch_bounds__(192) void conv_last_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ part, int batch, int h, int wd, int rows_per_block) {
     const long rows_total = (long)batch * h;
     const long row0 = (long)blockIdx.x * rows_per_block;
     long row1 = row0 + rows_per_block;
     if (row1 > rows_total) row1 = rows_total;
-    // thread -> (tap, co, ci): ci fastest so that a wave reads 64 contiguous channels
-    float acc[3] = {0.f, 0.f, 0.f};
-    float bacc = 0.f;
+    const int tr = threadIdx.x >> 6, ci = threadIdx.x & 63;
+    float acc[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    float bacc[2] = {0.f, 0.f};
     for (long row = row0; row < row1; ++row) {
         const long n = row / h;
-        const int y = (int)(row % h);
-        const float* __restrict__ d = dy + n * 2 * h * (long)wd;
+        const int y = (int)(row - n * h);
+        const float* __restrict__ d0 = dy + (n * 2 * h + y) * (long)wd;
+        const float* __restrict__ d1 = d0 + h * (long)wd;
+        const float* __restrict__ xr = x + (n * h + reflect1(y + tr - 1, h)) * (long)wd * 64 + ci;
+        float xm = xr[64], x0 = xr[0];                   // reflect(-1) = 1
+#pragma unroll 4
         for (int xq = 0; xq < wd; ++xq) {
-            const float g[2] = {d[(long)y * wd + xq], d[h * (long)wd + (long)y * wd + xq]};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int o = threadIdx.x + k * 384;      // 0 .. 1151 = tap * 128 + co * 64 + ci
-                const int t = o >> 7, co = (o >> 6) & 1, ci = o & 63;
-                const int ry = reflect1(y + t / 3 - 1, h), rx = reflect1(xq + t % 3 - 1, wd);
-                acc[k] += g[co] * x[((n * h + ry) * (long)wd + rx) * 64 + ci];
-            }
-            if (threadIdx.x < 2) bacc += g[threadIdx.x];
+            const float xp = xr[(long)reflect1(xq + 1, wd) * 64];
+            const float g0 = d0[xq], g1 = d1[xq];
+            acc[0][0] += g0 * xm; acc[0][1] += g1 * xm;
+            acc[1][0] += g0 * x0; acc[1][1] += g1 * x0;
+            acc[2][0] += g0 * xp; acc[2][1] += g1 * xp;
+            bacc[0] += g0; bacc[1] += g1;
+            xm = x0;
+            x0 = xp;
         }
     }
     float* __restrict__ dst = part + (long)blockIdx.x * 1154;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dst[threadIdx.x + k * 384] = acc[k];
-    if (threadIdx.x < 2) dst[1152 + threadIdx.x] = bacc;
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int co = 0; co < 2; ++co) dst[(tr * 3 + k) * 128 + co * 64 + ci] = acc[k][co];
+    if (threadIdx.x < 2) dst[1152 + threadIdx.x] = bacc[threadIdx.x];
 }
 __global__ __launch_bounds__(256) void conv_last_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                     float* __restrict__ db, int blocks) {
@@ -560,6 +579,66 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_fold_kernel(const float*
             s0 += v.x; s1 += v.y; s2 += v.z;
         }
     din[i] = w0[0] * s0 + w0[1] * s1 + w0[2] * s2;
+}
+
+// ---- calc_mean_std (function.py:4-12) of LARGE maps: the pixels split over blocks ------------------------------------------------
+// holo_channel_mean_std_* runs one block per (64 channels, image): right for the 32 x 32 map of the forward path, 16 blocks for a
+// 64-channel 256 x 256 map of the training losses (net.py:191-197).  Here grid (C/64, parts, B): float64 partial sums of 1024
+// pixels per block, added in part order by the finishing kernel (same formulas as adain.hip).
+constexpr int kWidePixels = 1024;
+__global__ __launch_bounds__(256) void mean_std_wide_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int hw, int c, int parts) {
+    __shared__ double s_sum[16][64];
+    __shared__ double s_sq[16][64];
+    const int tid = threadIdx.x;
+    const int cq = tid & 15, pg = tid >> 4;
+    const int c0 = blockIdx.x * 64, pt = blockIdx.y, b = blockIdx.z;
+    const float* __restrict__ xb = x + (size_t)b * hw * c + c0 + 4 * cq;
+    const int p0 = pt * kWidePixels;
+    const int p1 = p0 + kWidePixels < hw ? p0 + kWidePixels : hw;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int p = p0 + pg; p < p1; p += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * c);
+        s[0] += v.x; q[0] += (double)v.x * v.x;
+        s[1] += v.y; q[1] += (double)v.y * v.y;
+        s[2] += v.z; q[2] += (double)v.z * v.z;
+        s[3] += v.w; q[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_sum[pg][4 * cq + j] = s[j];
+        s_sq[pg][4 * cq + j] = q[j];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double ts = 0, tq = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            ts += s_sum[g][tid];
+            tq += s_sq[g][tid];
+        }
+        double* __restrict__ dst = part + (((size_t)b * parts + pt) * 2) * c + c0 + tid;
+        dst[0] = ts;
+        dst[c] = tq;
+    }
+}
+__global__ __launch_bounds__(256) void mean_std_wide_final_kernel(const double* __restrict__ part, float* __restrict__ mean,
+                                                                  float* __restrict__ stdv, int hw, int c, int parts, float eps, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / c;
+    const int ch = (int)(i - b * c);
+    double ts = 0, tq = 0;
+    for (int pt = 0; pt < parts; ++pt) {
+        const double* __restrict__ src = part + (((size_t)b * parts + pt) * 2) * c + ch;
+        ts += src[0];
+        tq += src[c];
+    }
+    const double n = (double)hw;
+    const double mu = ts / n;
+    double var = (tq - ts * mu) / (n - 1.0);            // unbiased (function.py:9)
+    var = var > 0 ? var : 0;
+    mean[i] = (float)mu;
+    stdv[i] = sqrtf((float)var + eps);
 }
 
 // ---- calc_mean_std backward (function.py:4-12): mean = sum x / HW, std = sqrt(var_unbiased + eps) ----------------------------
@@ -661,6 +740,31 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
 
 static inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
+constexpr int kFoldKeep = 64, kFoldBy = 32;
+// rows of scratch behind `rows` partial rows that fold_rows() may use
+static inline long fold_scratch_rows(long rows) {
+    long extra = 0;
+    while (rows > kFoldKeep) {
+        rows = (rows + kFoldBy - 1) / kFoldBy;
+        extra += rows;
+    }
+    return extra;
+}
+// folds part[rows][elems] (scratch directly behind it) until rows <= kFoldKeep; returns where the remaining rows are
+template <typename T>
+static const T* fold_rows(T* part, long elems, int& rows, hipStream_t stream) {
+    T* in = part;
+    T* out = part + (long)rows * elems;
+    while (rows > kFoldKeep) {
+        const int chunks = (rows + kFoldBy - 1) / kFoldBy;
+        hipLaunchKernelGGL((fold_rows_kernel<T>), dim3(blocks_for(elems), chunks), dim3(256), 0, stream, in, out, elems, rows, kFoldBy);
+        in = out;
+        out += (long)chunks * elems;
+        rows = chunks;
+    }
+    return in;
+}
+
 // partial layout of pix_gemm: slots = ceil(rows / rows_per_wave) rounded up to a multiple of 4 (4 waves per block)
 struct PixGemmPlan {
     int rows_per_wave, splits;
@@ -752,7 +856,7 @@ int holo_space_to_depth2_relu_f32(const float* dy, const float* y, float* g, int
 size_t holo_channel_sum_workspace_bytes(long rows, int c) {
     if (rows <= 0 || c <= 0) return 0;
     const int parts = rows < 4096 ? 1 : (rows < (1L << 20) ? 64 : 512);
-    return (size_t)parts * c * sizeof(double);
+    return (size_t)(parts + fold_scratch_rows(parts)) * c * sizeof(double);
 }
 int holo_channel_sum_f32(const float* x, float* out, long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
     HOLO_REQUIRE(x && out && workspace, HOLO_ERR_ARG, "holo_channel_sum_f32: null pointer");
@@ -760,7 +864,9 @@ int holo_channel_sum_f32(const float* x, float* out, long rows, int c, void* wor
     HOLO_REQUIRE(workspace_bytes >= holo_channel_sum_workspace_bytes(rows, c), HOLO_ERR_WORKSPACE, "holo_channel_sum_f32: workspace too small");
     const int parts = rows < 4096 ? 1 : (rows < (1L << 20) ? 64 : 512);
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(c / 64, parts), dim3(256), 0, as_stream(stream), x, static_cast<double*>(workspace), rows, c, parts);
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), static_cast<const double*>(workspace), out, c, parts);
+    int left = parts;
+    const double* folded = fold_rows(static_cast<double*>(workspace), c, left, as_stream(stream));
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), folded, out, c, left);
     return check_launch("holo_channel_sum_f32");
 }
 
@@ -769,7 +875,7 @@ size_t holo_pix_gemm_workspace_bytes(int batch, int h, int w, int mc, int nc, in
     const PixGemmPlan p = pix_gemm_plan(batch, h, mc, nc, pix_gemm_nt(nc, taps));
     long slots = p.slots;                              // room for either kernel's partial tiles
     if (pix_gemm_lds(w, mc, nc, taps)) slots = std::max(slots, pix_gemm_lds_plan(batch, h, w, mc, nc).units);
-    return (size_t)slots * mc * nc * taps * sizeof(float);
+    return (size_t)(slots + fold_scratch_rows(slots)) * mc * nc * taps * sizeof(float);
 }
 /* out[m][n][tap] = sum over the B*h*w pixels of P[pixel][m] * Q[reflect(pixel + tap)][n]; taps = 9 (3x3, tap = ky*3+kx, reflected
  * neighbour) or 1 (the pixel itself).  P: (B, h + 2*p_border, w + 2*p_border, mc) NHWC read at its interior, Q: (B, h, w, nc). */
@@ -786,7 +892,9 @@ int holo_pix_gemm_f32(const float* p, int p_border, const float* q, float* out, 
         HOLO_REQUIRE(lp.units <= 65535, HOLO_ERR_ARG, "holo_pix_gemm_f32: %ld work units (grid limit 65535)", lp.units);
         hipLaunchKernelGGL(pix_gemm9_lds_kernel, dim3(mc / 64, nc / 64, (unsigned)lp.units), dim3(256), 0, as_stream(stream), p, p_border, q, part,
                            h, w, mc, nc, lp.rows_per_unit, lp.groups);
-        hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), part, out, elems, (int)lp.units, taps, 1);
+        int left = (int)lp.units;
+        const float* folded = fold_rows(part, elems, left, as_stream(stream));
+        hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), folded, out, elems, left, taps, 1);
         return check_launch("holo_pix_gemm_f32");
     }
     const int nt = pix_gemm_nt(nc, taps);
@@ -798,15 +906,17 @@ int holo_pix_gemm_f32(const float* p, int p_border, const float* q, float* out, 
         hipLaunchKernelGGL((pix_gemm_kernel<1, 4>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
     else
         hipLaunchKernelGGL((pix_gemm_kernel<1, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
-    hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), part, out, elems, (int)pl.slots, taps, 0);
+    int left = (int)pl.slots;
+    const float* folded = fold_rows(part, elems, left, as_stream(stream));
+    hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), folded, out, elems, left, taps, 0);
     return check_launch("holo_pix_gemm_f32");
 }
 
 size_t holo_conv_last_bwd_workspace_bytes(int batch, int h, int w) {
     if (batch <= 0 || h <= 0 || w <= 0) return 0;
     const long rows = (long)batch * h;
-    const long blocks = rows < 2048 ? rows : 2048;
-    return (size_t)blocks * 1154 * sizeof(float);
+    const long blocks = rows < 8192 ? rows : 8192;
+    return (size_t)(blocks + fold_scratch_rows(blocks)) * 1154 * sizeof(float);
 }
 /* decoder[36:38] backward: dy (B,2,h,w) planes; x (B,h,w,64) the layer's input; dxp (B,h+2,w+2,64) the data gradient on the padded
  * domain (fold with holo_fold_reflect_f32, border 1), dw (2,64,3,3), db (2).  dxp / dw+db may be NULL to skip either part. */
@@ -822,11 +932,13 @@ int holo_conv_last_bwd_f32(const float* dy, const float* x_nhwc, const float* w_
         HOLO_REQUIRE(db && x_nhwc && workspace, HOLO_ERR_ARG, "holo_conv_last_bwd_f32: weight gradient needs x, db and a workspace");
         HOLO_REQUIRE(workspace_bytes >= holo_conv_last_bwd_workspace_bytes(batch, h, w), HOLO_ERR_WORKSPACE, "holo_conv_last_bwd_f32: workspace too small");
         const long rows = (long)batch * h;
-        const int blocks = (int)(rows < 2048 ? rows : 2048);
+        const int blocks = (int)(rows < 8192 ? rows : 8192);
         const int rpb = (int)((rows + blocks - 1) / blocks);
         const int nb = (int)((rows + rpb - 1) / rpb);
-        hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(nb), dim3(384), 0, as_stream(stream), x_nhwc, dy, static_cast<float*>(workspace), batch, h, w, rpb);
-        hipLaunchKernelGGL(conv_last_wgrad_final_kernel, dim3(5), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), dw, db, nb);
+        hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(nb), dim3(192), 0, as_stream(stream), x_nhwc, dy, static_cast<float*>(workspace), batch, h, w, rpb);
+        int left = nb;
+        const float* folded = fold_rows(static_cast<float*>(workspace), 1154, left, as_stream(stream));
+        hipLaunchKernelGGL(conv_last_wgrad_final_kernel, dim3(5), dim3(256), 0, as_stream(stream), folded, dw, db, left);
     }
     return check_launch("holo_conv_last_bwd_f32");
 }
@@ -843,6 +955,30 @@ int holo_conv_first_dgrad_f32(const float* da, const float* w0, const float* w1,
     const long t = (long)batch * h * w;
     hipLaunchKernelGGL(conv_first_dgrad_fold_kernel, dim3(blocks_for(t)), dim3(256), 0, as_stream(stream), static_cast<const float*>(workspace), w0, din, h, w, t);
     return check_launch("holo_conv_first_dgrad_f32");
+}
+
+size_t holo_channel_mean_std_wide_workspace_bytes(int batch, int hw, int c) {
+    if (batch <= 0 || hw <= 0 || c <= 0) return 0;
+    const size_t parts = (size_t)(hw + holo::kWidePixels - 1) / holo::kWidePixels;
+    return (size_t)batch * parts * 2 * c * sizeof(double);
+}
+/* calc_mean_std (function.py:4-12) of an NHWC fp32 map with the pixels split over blocks (large maps at small batch: the training
+ * losses, net.py:191-197); same formulas as holo_channel_mean_std_f32, partial sums added in a fixed order */
+int holo_channel_mean_std_wide_f32(const float* x_nhwc, float* mean, float* std, int batch, int hw, int c, float eps, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    HOLO_REQUIRE(x_nhwc && mean && std && workspace, HOLO_ERR_ARG, "holo_channel_mean_std_wide_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && batch <= 65535 && hw >= 2 && c > 0 && c % 64 == 0, HOLO_ERR_ARG,
+                 "holo_channel_mean_std_wide_f32: batch=%d hw=%d c=%d (c must be a multiple of 64, batch <= 65535)", batch, hw, c);
+    HOLO_REQUIRE(workspace_bytes >= holo_channel_mean_std_wide_workspace_bytes(batch, hw, c), HOLO_ERR_WORKSPACE,
+                 "holo_channel_mean_std_wide_f32: workspace too small");
+    const int parts = (hw + kWidePixels - 1) / kWidePixels;
+    HOLO_REQUIRE(parts <= 65535, HOLO_ERR_ARG, "holo_channel_mean_std_wide_f32: hw=%d too large", hw);
+    hipLaunchKernelGGL(mean_std_wide_partial_kernel, dim3(c / 64, parts, batch), dim3(256), 0, as_stream(stream), x_nhwc,
+                       static_cast<double*>(workspace), hw, c, parts);
+    const long total = (long)batch * c;
+    hipLaunchKernelGGL(mean_std_wide_final_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream),
+                       static_cast<const double*>(workspace), mean, std, hw, c, parts, eps, total);
+    return check_launch("holo_channel_mean_std_wide_f32");
 }
 
 int holo_mean_std_bwd_f32(const float* x_nhwc, const float* mean, const float* stdv, const float* dmean, const float* dstd, float* dx,

@@ -683,6 +683,24 @@ def conv_first_dgrad(da_nhwc, w0, w1) -> torch.Tensor:
     return din
 
 
+WIDE_STATS_MIN_HW = 16384
+
+
+def channel_mean_std_wide(x_nhwc: torch.Tensor, eps: float = 1e-5):
+    """function.py:4-12 on a large NHWC fp32 map, the pixels split over blocks (training losses at small batch)."""
+    _req(x_nhwc)
+    x_nhwc = _f32c(x_nhwc)
+    b, h, w, c = x_nhwc.shape
+    mean = torch.empty((b, c), dtype=torch.float32, device=x_nhwc.device)
+    std = torch.empty_like(mean)
+    n = lib.holo_channel_mean_std_wide_workspace_bytes(b, h * w, c)
+    ws = _ws(n, x_nhwc.device)
+    _launch("holo_channel_mean_std_wide_f32", lambda: lib.holo_channel_mean_std_wide_f32(x_nhwc.data_ptr(), mean.data_ptr(), std.data_ptr(), b, h * w, c,
+                                                                                         float(eps), ws.data_ptr(), n, _stream()),
+            nbytes=4.0 * x_nhwc.numel())
+    return mean, std
+
+
 def mean_std_bwd(x_nhwc, mean, std, dmean, dstd) -> torch.Tensor:
     """calc_mean_std backward on NHWC fp32: mean/std/dmean/dstd (B,C)."""
     _req(x_nhwc, mean, std, dmean, dstd)

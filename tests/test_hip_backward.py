@@ -123,6 +123,22 @@ def test_first_and_last_step(ag, dev, b, h, w):
     assert rel_err(wld.grad.cpu(), wlr.grad) < 2e-5 and rel_err(bld.grad.cpu(), blr.grad) < 2e-5
 
 
+def test_mean_std_of_a_large_map_splits_the_pixels(ag, dev):
+    """above ops.WIDE_STATS_MIN_HW pixels MeanStd runs the pixel-split kernel: same values as the one-block-per-image kernel"""
+    from style_transfer_based_holographic_imaging_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(2, 130, 131, 64, generator=g) * 1.5 + 0.7).to(dev)          # 17030 pixels: 17 parts, the last one partial
+    assert x.shape[1] * x.shape[2] > ops.WIDE_STATS_MIN_HW
+    m0, s0 = ops.channel_mean_std(x)
+    m1, s1 = ops.channel_mean_std_wide(x)
+    ref = x.double().cpu().view(2, -1, 64)
+    assert rel_err(m1.cpu(), ref.mean(1)) < 1e-6 and rel_err(s1.cpu(), (ref.var(1) + 1e-5).sqrt()) < 1e-6
+    assert (m0 - m1).abs().max() <= 1.2e-7 * m0.abs().max() and (s0 - s1).abs().max() <= 1.2e-7 * s0.abs().max()   # one ulp of fp32
+    xd = x.clone().requires_grad_()
+    md, sd_ = ag.MeanStd.apply(xd, 1e-5)
+    assert torch.equal(md, m1) and torch.equal(sd_, s1)
+
+
 def test_mean_std_and_distance_head(ag, dev):
     import sys
     from conftest import REPO

@@ -108,10 +108,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // NORM: the input rows are raw Linear outputs, normalised + ReLU'd on load.  TWO: row b = [x[b][0..k1) | x2[b][0..k-k1)].
-// A block = 8 samples x 16 output features: its four waves first bring the 8 input rows into LDS (two rows per wave, normalised
-// there if NORM), then every wave runs 4 features against all 8 rows — a row is fetched (and normalised) once per block and 16
-// features instead of once per wave and feature, and a lane has its 16 weight loads in flight at once.
-constexpr int kHeadFeat = 4;      // output features per wave
+// A block = 8 samples x (4 waves x kHeadFeat) output features: every wave requests its weights, then the four waves bring the
+// 8 input rows into LDS (two rows per wave, normalised there if NORM) and every wave runs its features against all 8 rows — a row
+// is fetched (and normalised) once per block, and the weight latency runs beside the staging instead of behind it.
+#ifndef HOLO_HEAD_FEAT
+#define HOLO_HEAD_FEAT 2
+#endif
+constexpr int kHeadFeat = HOLO_HEAD_FEAT;      // output features per wave (2: 128 blocks for the 1024-feature layers)
 template <bool NORM, bool TWO>
 __global__ __launch_bounds__(256) void head_linear_kernel(const float* __restrict__ x, const float* __restrict__ x2, int k1,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
@@ -120,6 +123,17 @@ __global__ __launch_bounds__(256) void head_linear_kernel(const float* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = blockIdx.y * kBT;
     constexpr int kQ = kHeadMaxK / 256;    // float4 steps per lane and row
+    // the wave's weights first: they do not depend on the rows, so their latency runs beside the staging (and normalising) below
+    const int on0 = (blockIdx.x * 4 + wave) * kHeadFeat;
+    float4 wv[kQ][kHeadFeat];
+#pragma unroll
+    for (int q = 0; q < kQ; ++q)
+#pragma unroll
+        for (int f = 0; f < kHeadFeat; ++f) {
+            const int kk = lane * 4 + 256 * q;
+            const int on = on0 + f < n ? on0 + f : n - 1;
+            wv[q][f] = kk < k ? *reinterpret_cast<const float4*>(w + (size_t)on * k + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     // ---- the block's 8 rows -> LDS (wave w: rows 2w, 2w+1) ----
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
@@ -160,8 +174,7 @@ __global__ __launch_bounds__(256) void head_linear_kernel(const float* __restric
         for (int q = 0; q < kQ; ++q) *reinterpret_cast<float4*>(&rows[i][lane * 4 + 256 * q]) = xv[q];
     }
     __syncthreads();
-    // ---- 4 features per wave against the 8 rows ----
-    const int on0 = (blockIdx.x * 4 + wave) * kHeadFeat;
+    // ---- kHeadFeat features per wave against the 8 rows ----
     float acc[kHeadFeat][kBT];
 #pragma unroll
     for (int f = 0; f < kHeadFeat; ++f)
@@ -171,21 +184,15 @@ __global__ __launch_bounds__(256) void head_linear_kernel(const float* __restric
     for (int q = 0; q < kQ; ++q) {
         const int kk = lane * 4 + 256 * q;
         if (kk < k) {
-            float4 wv[kHeadFeat];
-#pragma unroll
-            for (int f = 0; f < kHeadFeat; ++f) {
-                const int on = on0 + f < n ? on0 + f : n - 1;
-                wv[f] = *reinterpret_cast<const float4*>(w + (size_t)on * k + kk);
-            }
 #pragma unroll
             for (int i = 0; i < kBT; ++i) {
                 const float4 xv = *reinterpret_cast<const float4*>(&rows[i][kk]);
 #pragma unroll
                 for (int f = 0; f < kHeadFeat; ++f) {   // one explicit FMA chain per (feature, sample slot), as in linear_kernel
-                    acc[f][i] = fmaf(xv.x, wv[f].x, acc[f][i]);
-                    acc[f][i] = fmaf(xv.y, wv[f].y, acc[f][i]);
-                    acc[f][i] = fmaf(xv.z, wv[f].z, acc[f][i]);
-                    acc[f][i] = fmaf(xv.w, wv[f].w, acc[f][i]);
+                    acc[f][i] = fmaf(xv.x, wv[q][f].x, acc[f][i]);
+                    acc[f][i] = fmaf(xv.y, wv[q][f].y, acc[f][i]);
+                    acc[f][i] = fmaf(xv.z, wv[q][f].z, acc[f][i]);
+                    acc[f][i] = fmaf(xv.w, wv[q][f].w, acc[f][i]);
                 }
             }
         }

@@ -214,3 +214,44 @@ def test_net_forward_gradients_against_reference_golden(golden, dev):
     with torch.no_grad():
         obj2 = objective_of(network(content, style, 0.6, True, True))
     assert float(obj2) < float(obj)
+
+
+def test_gradients_at_benchmark_size_against_aten_on_the_device(dev):
+    """4 x 256^2 — the maps of the benchmarked size: weight gradients on the LDS-staged kernel at widths 256 / 128 / 64 / 32,
+    pixel-split statistics, Winograd data gradients — against torch.autograd over the oracle's restatement run with aten on the
+    same device (too large for the CPU suite; the small-size tests above pin the oracle's gradients to the reference's own)."""
+    import os
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import holo_oracle as orc
+    from hip_helpers import build_network
+    from style_transfer_based_holographic_imaging_amd import synth
+    network, _ = build_network(0)
+    params = dict(("decoder." + k, p) for k, p in network.decoder.named_parameters())
+    params.update(("distance_g." + k, p) for k, p in network.distance_g.named_parameters())
+    for p in params.values():
+        p.requires_grad_(True)
+    ph = synth.synthetic_phase_objects(8, 256, seed=11)
+    holo = (0.3 + 0.6 * ph).to(dev)
+    content, style = holo[:4].contiguous(), holo[4:].contiguous()
+
+    def objective(out):
+        lc, ls, g_t, g_ph, s_re, d_c, d_s = out
+        return lc + 10.0 * ls + (s_re - style).pow(2).mean() + g_ph.pow(2).mean() + (d_c - 0.5).pow(2).mean() + (d_s - 0.2).pow(2).mean()
+
+    obj = objective(network(content, style, 0.8, True, True))
+    obj.backward()
+    vgg_sd, dec_sd, dist_sd = synth.synthetic_state_dicts(0)
+    vgg = {k: v.to(dev) for k, v in vgg_sd.items()}
+    dec = {k: v.to(dev).requires_grad_() for k, v in dec_sd.items()}
+    dist = {k: v.to(dev).requires_grad_() for k, v in dist_sd.items()}
+    ref = objective(orc.net_forward(content, style, vgg, dec, dist, 0.8, True, True))
+    ref.backward()
+    assert abs(float(obj.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach()))
+    want = {"decoder." + k: v.grad for k, v in dec.items()}
+    want.update({"distance_g." + k: v.grad for k, v in dist.items()})
+    assert set(want) == set(params)
+    worst = max(rel_err(params[k].grad.cpu(), want[k].cpu()) for k in want)
+    print(f"worst relative gradient deviation from aten at 4 x 256^2: {worst:.2e}")
+    assert worst < 3e-4

@@ -81,6 +81,14 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 
 // ReflectionPad2d(1) index: -1 -> 1, n -> n-2 (n >= 2); anything further out is clamped so that
 // tile overhang past the image stays a valid (masked-at-store) address.
+// orders a wave's LDS reads behind its own earlier LDS writes (wave-private regions: the LDS unit executes one wave's DS
+// instructions in order, so no block barrier is needed)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int reflect1(int i, int n) {
     i = i < 0 ? -i : i;
     i = i >= n ? 2 * n - 2 - i : i;

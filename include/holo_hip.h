@@ -269,11 +269,15 @@ int holo_maxpool2x2_f32(const float* x_nhwc, float* y_nhwc, int batch, int h, in
  * dy routed through the max-pool (y_pool != NULL: dy and y_pool are (B,ceil(h/2),ceil(w/2),c); the first maximum of a window
  * in scan order takes the gradient, as torch's stored argmax) and masked by the ReLU (relu != 0: y_act > 0); y_act (B,h,w,c) is
  * the layer's post-ReLU, pre-pool output */
+/* pitch_rows: rows from one image's block of out_padded to the next; 0 = h + 2*border (separate blocks).  Less (down to
+ * h + border) = the TALL layout: neighbouring images share their zero rows, and the batch is one image of
+ * (B-1)*pitch_rows + h + 2*border rows for the convolution that follows (no per-image round-up to whole tiles) */
 int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float* y_pool, float* out_padded, int batch,
-                               int h, int w, int c, int relu, int border, void* stream);
+                               int h, int w, int c, int relu, int border, int pitch_rows, void* stream);
 /* adjoint of ReflectionPad2d(1): dx (B,h,w,c) = interior of dxp (B,h+2*border,w+2*border,c) plus its pad ring (padded row -1
- * onto row 1, row h onto row h-2, likewise columns); border = 1 or 2 */
-int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, void* stream);
+ * onto row 1, row h onto row h-2, likewise columns); border = 1 or 2; pitch_rows as above (0 = h + 2*border) */
+int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, int pitch_rows,
+                          void* stream);
 /* ConvTranspose2d(k2,s2)+ReLU backward helper: g (B,h,w,4c), g[..,q*c+ch] = dy[n,2Y+dy,2X+dx,ch] * (y > 0), q = dy*2+dx */
 int holo_space_to_depth2_relu_f32(const float* dy, const float* y, float* g, int batch, int h, int w, int c, int relu,
                                   void* stream);
@@ -282,10 +286,11 @@ size_t holo_channel_sum_workspace_bytes(long rows, int c);
 int holo_channel_sum_f32(const float* x, float* out, long rows, int c, void* workspace, size_t workspace_bytes, void* stream);
 /* out[m][n][tap] = sum over the B*h*w pixels of P[pixel][m] * Q[reflect(pixel + tap)][n]: weight gradients as a GEMM whose K runs
  * over pixels (v_mfma_f32_32x32x2_f32, deterministic).  P (B,h+2*p_border,w+2*p_border,mc) read at its interior, Q (B,h,w,nc),
- * taps = 9 (tap = ky*3+kx, reflected neighbour: out is the OIHW gradient for m = Cout, n = Cin) or 1; mc, nc % 32 == 0 */
+ * taps = 9 (tap = ky*3+kx, reflected neighbour: out is the OIHW gradient for m = Cout, n = Cin) or 1; mc, nc % 32 == 0;
+ * p_pitch_rows: rows between the images' blocks of P (0 = h + 2*p_border; the tall layout of holo_relu_pool_bwd_pad_f32) */
 size_t holo_pix_gemm_workspace_bytes(int batch, int h, int w, int mc, int nc, int taps);
-int holo_pix_gemm_f32(const float* p, int p_border, const float* q, float* out, int batch, int h, int w, int mc, int nc,
-                      int taps, void* workspace, size_t workspace_bytes, void* stream);
+int holo_pix_gemm_f32(const float* p, int p_border, int p_pitch_rows, const float* q, float* out, int batch, int h, int w,
+                      int mc, int nc, int taps, void* workspace, size_t workspace_bytes, void* stream);
 /* decoder[36:38] (net.py:72-73) backward: dy (B,2,h,w) planes, x (B,h,w,64) the layer's input; dxp (B,h+2,w+2,64) = data gradient
  * on the padded domain (fold with holo_fold_reflect_f32, border 1) or NULL; dw (2,64,3,3) + db (2) or NULL */
 size_t holo_conv_last_bwd_workspace_bytes(int batch, int h, int w);

@@ -55,14 +55,18 @@ class ConvStep(torch.autograd.Function):
         cout = w.shape[0]
         if y_act is None:
             y_act = x.new_empty((b, h, wd, cout))       # shape carrier only (neither ReLU nor pool reads it)
-        dap = ops.relu_pool_bwd_pad(dy.contiguous(), y_act, y_pool, ctx.relu, 2)          # (B, h+4, w+4, Cout)
+        # the embedded gradient as ONE tall image (neighbours share their zero rows) while it stays under the convolution
+        # kernels' 2^30 elements per image: the data-gradient convolution then rounds the batch, not every image, up to whole tiles
+        # (32 x 32 maps in 32 x 16-pixel tiles: 54 tiles for 16 images instead of 96)
+        tall = b > 1 and ((b - 1) * (h + 2) + h + 4) * (wd + 4) * max(cin, cout) < (1 << 30)
+        dap = ops.relu_pool_bwd_pad(dy.contiguous(), y_act, y_pool, ctx.relu, 2, tall=tall)   # (B, h+4, w+4, Cout) | (1, B(h+2)+2, w+4, Cout)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if cin % 64 != 0:
                 raise NotImplementedError(f"data gradient of a {cin} -> {cout} convolution: the forward kernels need Cout % 64 == 0")
             wd_t = w.flip(2, 3).transpose(0, 1).contiguous()                               # (Cin, Cout, 3, 3): full correlation
-            dxp = _conv_fwd(dap, wd_t, torch.zeros(cin, device=x.device), False)          # (B, h+4, w+4, Cin)
-            dx = ops.fold_reflect(dxp, h, wd, 2)
+            dxp = _conv_fwd(dap, wd_t, torch.zeros(cin, device=x.device), False)          # same shape as dap, Cin channels
+            dx = ops.fold_reflect(dxp, h, wd, 2, batch=b if tall else 0)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = ops.pix_gemm(dap, 2, x, 9).view(cout, cin, 3, 3)
             db = ops.channel_sum(dap)

@@ -55,18 +55,23 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict
 //   g = pool ? (y_act[y,x] is the FIRST maximum of its 2x2 window in scan order ? dy[y/2, x/2] : 0) : dy[y, x]
 //   out = relu ? (y_act > 0 ? g : 0) : g                      (torch: max_pool2d_backward routes to the stored argmax, the first
 //                                                              strict maximum; threshold_backward masks with the output > 0)
+// pitch = rows from one image's block to the next: h + 2*border (separate blocks), or less — down to h + border — for the TALL
+// layout, where consecutive images share their zero rows (image n's lower border rows are image n + 1's upper ones): the whole batch
+// is then ONE image of (B - 1) * pitch + h + 2*border rows for the convolution that follows, which no longer rounds every image up
+// to whole tiles separately.
 __global__ __launch_bounds__(256) void relu_pool_bwd_pad_kernel(const float* __restrict__ dy, const float* __restrict__ y_act,
-                                                                const float* __restrict__ y_pool, float* __restrict__ out, int h,
-                                                                int w, int c4, int relu, int border, long total) {
+                                                                const float* __restrict__ y_pool, float* __restrict__ out, int batch,
+                                                                int h, int w, int c4, int relu, int border, int pitch, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int hp = h + 2 * border, wp = w + 2 * border;
+    const int wp = w + 2 * border;
     const int cq = (int)(i % c4);
     long r = i / c4;
     const int xp = (int)(r % wp);
-    r /= wp;
-    const int yp = (int)(r % hp);
-    const long n = r / hp;
+    r /= wp;                                        // row of the whole output
+    long n = r / pitch;
+    if (n > batch - 1) n = batch - 1;
+    const int yp = (int)(r - n * pitch);
     const int y = yp - border, x = xp - border;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (y >= 0 && y < h && x >= 0 && x < w) {
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void relu_pool_bwd_pad_kernel(const float* __r
 
 // ---- adjoint of ReflectionPad2d(1): fold the pad ring of dXp (padded coordinates -1 .. h at index + border) onto the interior ----
 __global__ __launch_bounds__(256) void fold_reflect_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int h, int w, int c4,
-                                                           int border, long total) {
+                                                           int border, int pitch, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int cq = (int)(i % c4);
@@ -113,8 +118,8 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel(const float* __restri
     r /= w;
     const int y = (int)(r % h);
     const long n = r / h;
-    const int hp = h + 2 * border, wp = w + 2 * border;
-    const float4* src = reinterpret_cast<const float4*>(dxp) + n * hp * (long)wp * c4;
+    const int wp = w + 2 * border;
+    const float4* src = reinterpret_cast<const float4*>(dxp) + n * pitch * (long)wp * c4;
     // padded rows that reflect onto row y: y itself, -1 if y == 1, h if y == h - 2
     int ys[3], xs[3], ny = 0, nx = 0;
     ys[ny++] = y;
@@ -212,7 +217,7 @@ struct PixFrag {
 template <int TAPS, int NT>
 __global__ __launch_bounds__(256, 2) void pix_gemm_kernel(const float* __restrict__ p, int pb, const float* __restrict__ q,
                                                           float* __restrict__ part, int batch, int h, int w, int mc, int nc,
-                                                          int rows_per_wave) {
+                                                          int rows_per_wave, int ppitch) {
     constexpr int NB = TAPS * NT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hs = lane >> 5;
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void pix_gemm_kernel(const float* __restric
     for (int t = 0; t < NB; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    const int hp = h + 2 * pb, wp = w + 2 * pb;
+    const int hp = ppitch, wp = w + 2 * pb;          // image n's block of P starts at row n * ppitch
     const int xsteps = (w + 1) >> 1;
     const int steps = row1 > row0 ? (int)(row1 - row0) * xsteps : 0;
     if (steps > 0) {
@@ -318,7 +323,7 @@ constexpr int kPgLdsBytes = 2 * kPgPBytes + 4 * kPgQBytes;
 
 __global__ __launch_bounds__(256, 2) void pix_gemm9_lds_kernel(const float* __restrict__ p, int pb, const float* __restrict__ q,
                                                                float* __restrict__ part, int h, int w, int mc, int nc,
-                                                               int rows_per_unit, int groups) {
+                                                               int rows_per_unit, int groups, int ppitch) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kPgLdsBytes];
     const float* sf = reinterpret_cast<const float*>(smem);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void pix_gemm9_lds_kernel(const float* __re
     int y1 = y0 + rows_per_unit;
     if (y1 > h) y1 = h;
     const int cx0 = c * kPgChunk;
-    const int hp = h + 2 * pb, wp = w + 2 * pb;
+    const int hp = ppitch, wp = w + 2 * pb;          // image n's block of P starts at row n * ppitch
     const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
 
 #define PG_GLDS(sbase_, voff_, ldst_)                                                                      \
@@ -826,22 +831,29 @@ int holo_maxpool2x2_f32(const float* x_nhwc, float* y_nhwc, int batch, int h, in
 }
 
 int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float* y_pool, float* out_padded, int batch, int h, int w,
-                               int c, int relu, int border, void* stream) {
+                               int c, int relu, int border, int pitch_rows, void* stream) {
     HOLO_REQUIRE(dy && out_padded && (y_act || (!relu && !y_pool)), HOLO_ERR_ARG, "holo_relu_pool_bwd_pad_f32: null pointer");
     HOLO_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && border >= 0 && border <= 2, HOLO_ERR_ARG,
                  "holo_relu_pool_bwd_pad_f32: batch=%d h=%d w=%d c=%d border=%d", batch, h, w, c, border);
-    const long total = (long)batch * (h + 2 * border) * (w + 2 * border) * (c / 4);
-    hipLaunchKernelGGL(relu_pool_bwd_pad_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dy, y_act, y_pool, out_padded, h, w,
-                       c / 4, relu, border, total);
+    const int pitch = pitch_rows > 0 ? pitch_rows : h + 2 * border;
+    HOLO_REQUIRE(pitch >= h + border && pitch <= h + 2 * border, HOLO_ERR_ARG,
+                 "holo_relu_pool_bwd_pad_f32: pitch_rows=%d outside [h + border, h + 2*border] = [%d, %d]", pitch_rows, h + border, h + 2 * border);
+    const long rows = (long)(batch - 1) * pitch + h + 2 * border;
+    const long total = rows * (w + 2 * border) * (c / 4);
+    hipLaunchKernelGGL(relu_pool_bwd_pad_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dy, y_act, y_pool, out_padded, batch,
+                       h, w, c / 4, relu, border, pitch, total);
     return check_launch("holo_relu_pool_bwd_pad_f32");
 }
 
-int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, void* stream) {
+int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, int pitch_rows, void* stream) {
     HOLO_REQUIRE(dxp && dx, HOLO_ERR_ARG, "holo_fold_reflect_f32: null pointer");
     HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && c > 0 && c % 4 == 0 && border >= 1 && border <= 2, HOLO_ERR_ARG,
                  "holo_fold_reflect_f32: batch=%d h=%d w=%d c=%d border=%d (reflection padding needs h,w >= 2)", batch, h, w, c, border);
+    const int pitch = pitch_rows > 0 ? pitch_rows : h + 2 * border;
+    HOLO_REQUIRE(pitch >= h + border && pitch <= h + 2 * border, HOLO_ERR_ARG,
+                 "holo_fold_reflect_f32: pitch_rows=%d outside [h + border, h + 2*border] = [%d, %d]", pitch_rows, h + border, h + 2 * border);
     const long total = (long)batch * h * w * (c / 4);
-    hipLaunchKernelGGL(fold_reflect_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dxp, dx, h, w, c / 4, border, total);
+    hipLaunchKernelGGL(fold_reflect_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dxp, dx, h, w, c / 4, border, pitch, total);
     return check_launch("holo_fold_reflect_f32");
 }
 
@@ -879,19 +891,22 @@ size_t holo_pix_gemm_workspace_bytes(int batch, int h, int w, int mc, int nc, in
 }
 /* out[m][n][tap] = sum over the B*h*w pixels of P[pixel][m] * Q[reflect(pixel + tap)][n]; taps = 9 (3x3, tap = ky*3+kx, reflected
  * neighbour) or 1 (the pixel itself).  P: (B, h + 2*p_border, w + 2*p_border, mc) NHWC read at its interior, Q: (B, h, w, nc). */
-int holo_pix_gemm_f32(const float* p, int p_border, const float* q, float* out, int batch, int h, int w, int mc, int nc, int taps,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+int holo_pix_gemm_f32(const float* p, int p_border, int p_pitch_rows, const float* q, float* out, int batch, int h, int w, int mc, int nc,
+                      int taps, void* workspace, size_t workspace_bytes, void* stream) {
     HOLO_REQUIRE(p && q && out && workspace, HOLO_ERR_ARG, "holo_pix_gemm_f32: null pointer");
     HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && mc > 0 && nc > 0 && mc % 32 == 0 && nc % 32 == 0 && (taps == 1 || taps == 9) && p_border >= 0,
                  HOLO_ERR_ARG, "holo_pix_gemm_f32: batch=%d h=%d w=%d mc=%d nc=%d taps=%d (channels %% 32, taps 1 | 9)", batch, h, w, mc, nc, taps);
     HOLO_REQUIRE(workspace_bytes >= holo_pix_gemm_workspace_bytes(batch, h, w, mc, nc, taps), HOLO_ERR_WORKSPACE, "holo_pix_gemm_f32: workspace too small");
+    const int ppitch = p_pitch_rows > 0 ? p_pitch_rows : h + 2 * p_border;
+    HOLO_REQUIRE(ppitch >= h + p_border && ppitch <= h + 2 * p_border, HOLO_ERR_ARG,
+                 "holo_pix_gemm_f32: p_pitch_rows=%d outside [h + border, h + 2*border] = [%d, %d]", p_pitch_rows, h + p_border, h + 2 * p_border);
     float* part = static_cast<float*>(workspace);
     const long elems = (long)mc * nc * taps;
     if (pix_gemm_lds(w, mc, nc, taps) && !pix_gemm_force_direct()) {
         const PixGemmLdsPlan lp = pix_gemm_lds_plan(batch, h, w, mc, nc);
         HOLO_REQUIRE(lp.units <= 65535, HOLO_ERR_ARG, "holo_pix_gemm_f32: %ld work units (grid limit 65535)", lp.units);
         hipLaunchKernelGGL(pix_gemm9_lds_kernel, dim3(mc / 64, nc / 64, (unsigned)lp.units), dim3(256), 0, as_stream(stream), p, p_border, q, part,
-                           h, w, mc, nc, lp.rows_per_unit, lp.groups);
+                           h, w, mc, nc, lp.rows_per_unit, lp.groups, ppitch);
         int left = (int)lp.units;
         const float* folded = fold_rows(part, elems, left, as_stream(stream));
         hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), folded, out, elems, left, taps, 1);
@@ -901,11 +916,11 @@ int holo_pix_gemm_f32(const float* p, int p_border, const float* q, float* out, 
     const PixGemmPlan pl = pix_gemm_plan(batch, h, mc, nc, nt);
     const dim3 grid(mc / 32, nc / (32 * nt), pl.splits);
     if (taps == 9)
-        hipLaunchKernelGGL((pix_gemm_kernel<9, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
+        hipLaunchKernelGGL((pix_gemm_kernel<9, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, ppitch);
     else if (nt == 4)
-        hipLaunchKernelGGL((pix_gemm_kernel<1, 4>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
+        hipLaunchKernelGGL((pix_gemm_kernel<1, 4>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, ppitch);
     else
-        hipLaunchKernelGGL((pix_gemm_kernel<1, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave);
+        hipLaunchKernelGGL((pix_gemm_kernel<1, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, ppitch);
     int left = (int)pl.slots;
     const float* folded = fold_rows(part, elems, left, as_stream(stream));
     hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), folded, out, elems, left, taps, 0);

@@ -272,8 +272,12 @@ int holo_maxpool2x2_f32(const float* x_nhwc, float* y_nhwc, int batch, int h, in
 /* pitch_rows: rows from one image's block of out_padded to the next; 0 = h + 2*border (separate blocks).  Less (down to
  * h + border) = the TALL layout: neighbouring images share their zero rows, and the batch is one image of
  * (B-1)*pitch_rows + h + 2*border rows for the convolution that follows (no per-image round-up to whole tiles) */
+/* dbias (c) or NULL: the bias gradient = sum of out_padded over its pixels, accumulated in the same pass (float64 partial sums,
+ * fixed order); needs a workspace of holo_relu_pool_bwd_pad_workspace_bytes(c) */
+size_t holo_relu_pool_bwd_pad_workspace_bytes(int c);
 int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float* y_pool, float* out_padded, int batch,
-                               int h, int w, int c, int relu, int border, int pitch_rows, void* stream);
+                               int h, int w, int c, int relu, int border, int pitch_rows, float* dbias, void* workspace,
+                               size_t workspace_bytes, void* stream);
 /* adjoint of ReflectionPad2d(1): dx (B,h,w,c) = interior of dxp (B,h+2*border,w+2*border,c) plus its pad ring (padded row -1
  * onto row 1, row h onto row h-2, likewise columns); border = 1 or 2; pitch_rows as above (0 = h + 2*border) */
 int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, int pitch_rows,

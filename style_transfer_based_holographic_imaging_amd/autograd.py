@@ -59,17 +59,22 @@ class ConvStep(torch.autograd.Function):
         # kernels' 2^30 elements per image: the data-gradient convolution then rounds the batch, not every image, up to whole tiles
         # (32 x 32 maps in 32 x 16-pixel tiles: 54 tiles for 16 images instead of 96)
         tall = b > 1 and ((b - 1) * (h + 2) + h + 4) * (wd + 4) * max(cin, cout) < (1 << 30)
-        dap = ops.relu_pool_bwd_pad(dy.contiguous(), y_act, y_pool, ctx.relu, 2, tall=tall)   # (B, h+4, w+4, Cout) | (1, B(h+2)+2, w+4, Cout)
-        dx = dw = db = None
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        fused_bias = need_w and 1024 % cout == 0                    # the bias gradient summed by the mask / pad pass itself
+        dap = ops.relu_pool_bwd_pad(dy.contiguous(), y_act, y_pool, ctx.relu, 2, tall=tall, with_bias=fused_bias)
+        dx = dw = db = None                                         # dap: (B, h+4, w+4, Cout) | (1, B(h+2)+2, w+4, Cout)
+        if fused_bias:
+            dap, db = dap
         if ctx.needs_input_grad[0]:
             if cin % 64 != 0:
                 raise NotImplementedError(f"data gradient of a {cin} -> {cout} convolution: the forward kernels need Cout % 64 == 0")
             wd_t = w.flip(2, 3).transpose(0, 1).contiguous()                               # (Cin, Cout, 3, 3): full correlation
             dxp = _conv_fwd(dap, wd_t, torch.zeros(cin, device=x.device), False)          # same shape as dap, Cin channels
             dx = ops.fold_reflect(dxp, h, wd, 2, batch=b if tall else 0)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if need_w:
             dw = ops.pix_gemm(dap, 2, x, 9).view(cout, cin, 3, 3)
-            db = ops.channel_sum(dap)
+            if db is None:
+                db = ops.channel_sum(dap)
         return dx, dw, db, None, None
 
 

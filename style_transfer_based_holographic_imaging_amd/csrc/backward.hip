@@ -61,50 +61,69 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict
 // to whole tiles separately.
 __global__ __launch_bounds__(256) void relu_pool_bwd_pad_kernel(const float* __restrict__ dy, const float* __restrict__ y_act,
                                                                 const float* __restrict__ y_pool, float* __restrict__ out, int batch,
-                                                                int h, int w, int c4, int relu, int border, int pitch, long total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+                                                                int h, int w, int c4, int relu, int border, int pitch, long total,
+                                                                double* __restrict__ bias_part) {
+    // grid-stride over the float4 elements; the stride is a multiple of c4 (c4 divides 256), so a thread stays on one channel quad
+    // and can keep that quad's running sum (the bias gradient = sum of the masked gradient over pixels) in float64
+    __shared__ double red[256][4];
+    double bsum[4] = {0, 0, 0, 0};
     const int wp = w + 2 * border;
-    const int cq = (int)(i % c4);
-    long r = i / c4;
-    const int xp = (int)(r % wp);
-    r /= wp;                                        // row of the whole output
-    long n = r / pitch;
-    if (n > batch - 1) n = batch - 1;
-    const int yp = (int)(r - n * pitch);
-    const int y = yp - border, x = xp - border;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (y >= 0 && y < h && x >= 0 && x < w) {
-        const float4* ya = reinterpret_cast<const float4*>(y_act) + n * h * (long)w * c4;
-        const float4 a = relu || y_pool ? ya[((long)y * w + x) * c4 + cq] : g;
-        if (y_pool) {
-            const int ho = (h + 1) >> 1, wo = (w + 1) >> 1;
-            const long po = (n * ho + (y >> 1)) * (long)wo + (x >> 1);
-            const float4 m = reinterpret_cast<const float4*>(y_pool)[po * c4 + cq];
-            const float4 d = reinterpret_cast<const float4*>(dy)[po * c4 + cq];
-            // earlier members of the window (scan order) that already hold the maximum take the gradient instead
-            bool e0 = false, e1 = false, e2 = false, e3 = false;
-            const int k = ((y & 1) << 1) | (x & 1);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cq = (int)(i % c4);                   // = threadIdx.x % c4 on every trip when c4 divides 256 (the bias sums rely on it)
+        long r = i / c4;
+        const int xp = (int)(r % wp);
+        r /= wp;                                        // row of the whole output
+        long n = r / pitch;
+        if (n > batch - 1) n = batch - 1;
+        const int yp = (int)(r - n * pitch);
+        const int y = yp - border, x = xp - border;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+            const float4* ya = reinterpret_cast<const float4*>(y_act) + n * h * (long)w * c4;
+            const float4 a = relu || y_pool ? ya[((long)y * w + x) * c4 + cq] : g;
+            if (y_pool) {
+                const int ho = (h + 1) >> 1, wo = (w + 1) >> 1;
+                const long po = (n * ho + (y >> 1)) * (long)wo + (x >> 1);
+                const float4 m = reinterpret_cast<const float4*>(y_pool)[po * c4 + cq];
+                const float4 d = reinterpret_cast<const float4*>(dy)[po * c4 + cq];
+                // earlier members of the window (scan order) that already hold the maximum take the gradient instead
+                bool e0 = false, e1 = false, e2 = false, e3 = false;
+                const int k = ((y & 1) << 1) | (x & 1);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (q < k) {
-                    const int yy = (y & ~1) + (q >> 1), xx = (x & ~1) + (q & 1);     // always inside the image for q < k
-                    const float4 v = ya[((long)yy * w + xx) * c4 + cq];
-                    e0 |= v.x == m.x; e1 |= v.y == m.y; e2 |= v.z == m.z; e3 |= v.w == m.w;
+                for (int q = 0; q < 3; ++q) {
+                    if (q < k) {
+                        const int yy = (y & ~1) + (q >> 1), xx = (x & ~1) + (q & 1);     // always inside the image for q < k
+                        const float4 v = ya[((long)yy * w + xx) * c4 + cq];
+                        e0 |= v.x == m.x; e1 |= v.y == m.y; e2 |= v.z == m.z; e3 |= v.w == m.w;
+                    }
                 }
+                g.x = (a.x == m.x && !e0) ? d.x : 0.f;
+                g.y = (a.y == m.y && !e1) ? d.y : 0.f;
+                g.z = (a.z == m.z && !e2) ? d.z : 0.f;
+                g.w = (a.w == m.w && !e3) ? d.w : 0.f;
+            } else {
+                g = reinterpret_cast<const float4*>(dy)[((n * h + y) * (long)w + x) * c4 + cq];
             }
-            g.x = (a.x == m.x && !e0) ? d.x : 0.f;
-            g.y = (a.y == m.y && !e1) ? d.y : 0.f;
-            g.z = (a.z == m.z && !e2) ? d.z : 0.f;
-            g.w = (a.w == m.w && !e3) ? d.w : 0.f;
-        } else {
-            g = reinterpret_cast<const float4*>(dy)[((n * h + y) * (long)w + x) * c4 + cq];
+            if (relu) {
+                g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+            }
         }
-        if (relu) {
-            g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+        reinterpret_cast<float4*>(out)[i] = g;
+        bsum[0] += g.x; bsum[1] += g.y; bsum[2] += g.z; bsum[3] += g.w;
+    }
+    if (bias_part) {              // block partial: the threads of a quad in thread order
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = bsum[j];
+        __syncthreads();
+        if (threadIdx.x < c4) {
+            double t[4] = {0, 0, 0, 0};
+            for (int k = threadIdx.x; k < 256; k += c4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] += red[k][j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias_part[(long)blockIdx.x * 4 * c4 + 4 * threadIdx.x + j] = t[j];
         }
     }
-    reinterpret_cast<float4*>(out)[i] = g;
 }
 
 // ---- adjoint of ReflectionPad2d(1): fold the pad ring of dXp (padded coordinates -1 .. h at index + border) onto the interior ----
@@ -746,6 +765,7 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
 static inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
 constexpr int kFoldKeep = 64, kFoldBy = 32;
+constexpr int kPadBlocks = 2048;     // blocks of the mask / pad kernel when it also sums the bias gradient
 // rows of scratch behind `rows` partial rows that fold_rows() may use
 static inline long fold_scratch_rows(long rows) {
     long extra = 0;
@@ -830,18 +850,31 @@ int holo_maxpool2x2_f32(const float* x_nhwc, float* y_nhwc, int batch, int h, in
     return check_launch("holo_maxpool2x2_f32");
 }
 
+size_t holo_relu_pool_bwd_pad_workspace_bytes(int c) {
+    return c > 0 ? (size_t)(holo::kPadBlocks + holo::fold_scratch_rows(holo::kPadBlocks)) * c * sizeof(double) : 0;
+}
 int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float* y_pool, float* out_padded, int batch, int h, int w,
-                               int c, int relu, int border, int pitch_rows, void* stream) {
+                               int c, int relu, int border, int pitch_rows, float* dbias, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     HOLO_REQUIRE(dy && out_padded && (y_act || (!relu && !y_pool)), HOLO_ERR_ARG, "holo_relu_pool_bwd_pad_f32: null pointer");
     HOLO_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && border >= 0 && border <= 2, HOLO_ERR_ARG,
                  "holo_relu_pool_bwd_pad_f32: batch=%d h=%d w=%d c=%d border=%d", batch, h, w, c, border);
     const int pitch = pitch_rows > 0 ? pitch_rows : h + 2 * border;
     HOLO_REQUIRE(pitch >= h + border && pitch <= h + 2 * border, HOLO_ERR_ARG,
                  "holo_relu_pool_bwd_pad_f32: pitch_rows=%d outside [h + border, h + 2*border] = [%d, %d]", pitch_rows, h + border, h + 2 * border);
+    HOLO_REQUIRE(256 % (c / 4) == 0 || !dbias, HOLO_ERR_ARG, "holo_relu_pool_bwd_pad_f32: the bias gradient needs c in {4,...,1024} with 1024 %% c == 0 (c=%d)", c);
+    HOLO_REQUIRE(!dbias || (workspace && workspace_bytes >= holo_relu_pool_bwd_pad_workspace_bytes(c)), HOLO_ERR_WORKSPACE,
+                 "holo_relu_pool_bwd_pad_f32: the bias gradient needs a workspace of %zu bytes", holo_relu_pool_bwd_pad_workspace_bytes(c));
     const long rows = (long)(batch - 1) * pitch + h + 2 * border;
     const long total = rows * (w + 2 * border) * (c / 4);
-    hipLaunchKernelGGL(relu_pool_bwd_pad_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dy, y_act, y_pool, out_padded, batch,
-                       h, w, c / 4, relu, border, pitch, total);
+    const unsigned blocks = blocks_for(total) < (unsigned)kPadBlocks || !dbias ? blocks_for(total) : (unsigned)kPadBlocks;
+    hipLaunchKernelGGL(relu_pool_bwd_pad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, y_act, y_pool, out_padded, batch,
+                       h, w, c / 4, relu, border, pitch, total, dbias ? static_cast<double*>(workspace) : nullptr);
+    if (dbias) {
+        int left = (int)blocks;
+        const double* folded = fold_rows(static_cast<double*>(workspace), c, left, as_stream(stream));
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), folded, dbias, c, left);
+    }
     return check_launch("holo_relu_pool_bwd_pad_f32");
 }
 

@@ -579,11 +579,12 @@ def maxpool2x2(x_nhwc: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def relu_pool_bwd_pad(dy, y_act, y_pool, relu: bool, border: int, tall: bool = False) -> torch.Tensor:
+def relu_pool_bwd_pad(dy, y_act, y_pool, relu: bool, border: int, tall: bool = False, with_bias: bool = False):
     """Gradient of a conv step's pre-activation embedded in a zero border: dy routed through the (optional) max-pool and masked
     by the (optional) ReLU.  y_act: (B,h,w,c) post-ReLU pre-pool output; dy, y_pool: pooled shape when y_pool is given.
     tall: ONE image (1, (B-1)*(h+border) + h + 2*border, w + 2*border, c) in which neighbouring images share their zero rows
-    (image n's block starts at row n*(h+border)) instead of (B, h+2*border, w+2*border, c)."""
+    (image n's block starts at row n*(h+border)) instead of (B, h+2*border, w+2*border, c).
+    with_bias: also returns the bias gradient (c), summed in the same pass."""
     _req(dy, y_act)
     dy, y_act = _f32c(dy), _f32c(y_act)
     b, h, w, c = y_act.shape
@@ -591,11 +592,15 @@ def relu_pool_bwd_pad(dy, y_act, y_pool, relu: bool, border: int, tall: bool = F
     pitch = h + border if tall else h + 2 * border
     shape = (1, (b - 1) * pitch + h + 2 * border, w + 2 * border, c) if tall else (b, h + 2 * border, w + 2 * border, c)
     out = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    dbias = torch.empty((c,), dtype=torch.float32, device=dy.device) if with_bias else None
+    n = lib.holo_relu_pool_bwd_pad_workspace_bytes(c) if with_bias else 0
+    ws = _ws(n, dy.device) if with_bias else None
     _launch("holo_relu_pool_bwd_pad_f32",
             lambda: lib.holo_relu_pool_bwd_pad_f32(dy.data_ptr(), y_act.data_ptr(), yp.data_ptr() if yp is not None else 0, out.data_ptr(),
-                                                   b, h, w, c, int(bool(relu)), int(border), int(pitch), _stream()),
+                                                   b, h, w, c, int(bool(relu)), int(border), int(pitch),
+                                                   dbias.data_ptr() if with_bias else 0, ws.data_ptr() if with_bias else 0, n, _stream()),
             nbytes=12.0 * b * h * w * c)
-    return out
+    return (out, dbias) if with_bias else out
 
 
 def fold_reflect(dxp, h: int, w: int, border: int, batch: int = 0) -> torch.Tensor:

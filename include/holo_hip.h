@@ -282,6 +282,12 @@ int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float*
  * onto row 1, row h onto row h-2, likewise columns); border = 1 or 2; pitch_rows as above (0 = h + 2*border) */
 int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, int pitch_rows,
                           void* stream);
+/* y (B,h,w,cout) = x (B,h,w,cin) . W[cin][cout] + bias [ReLU]: a plain 1x1 convolution on the one-tap MFMA GEMM of the transposed
+ * convolution (net.py:46-65 backward: the data gradient of ConvTranspose2d(k2,s2) is a 1x1 convolution of the space-to-depth
+ * gradient).  w_packed = holo_pack_convt2x2_weight_f32 of the (cin, cout/4, 2, 2) tensor T[k][c][dy][dx] = W[k][(2dy+dx)*cout/4 + c];
+ * cin % 16 == 0, cout % 64 == 0 */
+int holo_conv1x1_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc, int batch, int h, int w,
+                     int cin, int cout, int relu, void* stream);
 /* ConvTranspose2d(k2,s2)+ReLU backward helper: g (B,h,w,4c), g[..,q*c+ch] = dy[n,2Y+dy,2X+dx,ch] * (y > 0), q = dy*2+dx */
 int holo_space_to_depth2_relu_f32(const float* dy, const float* y, float* g, int batch, int h, int w, int c, int relu,
                                   void* stream);

@@ -7,8 +7,8 @@ forward AND backward are C-ABI calls (include/holo_hip.h, ABI 5; csrc/backward.h
   conv step      ReflPad + Conv3x3 [+ ReLU] [+ MaxPool ceil]
                  dX = fold_reflect( forward_conv( pad2(route/mask(dY)), flip(W)^T ) )      the data gradient runs on the FORWARD kernels
                  dW = pix_gemm(pad2(...), X, 9 taps),  db = channel_sum
-  convt step     ConvTranspose k2s2 [+ ReLU]:  G = space_to_depth(mask(dY));  dX = 1x1 conv of G (a centre-only 3x3 on the forward
-                 kernel);  dW = pix_gemm(X, G, 1 tap)
+  convt step     ConvTranspose k2s2 [+ ReLU]:  G = space_to_depth(mask(dY));  dX = 1x1 conv of G (the transposed convolution's own
+                 one-tap MFMA GEMM, stored plainly);  dW = pix_gemm(X, G, 1 tap)
   first / last   the skinny layers: VALU kernels (first: data gradient only, the encoder is frozen, net.py:167-170)
   mean_std       calc_mean_std (function.py:4-12)
   distance head  Linear / per-row norm + ReLU / sigmoid, layer by layer (net.py:288-308)
@@ -100,9 +100,8 @@ class ConvTStep(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if cin % 64 != 0:
                 raise NotImplementedError("data gradient of the transposed convolution needs Cin % 64 == 0")
-            w3 = torch.zeros((cin, 4 * cout, 3, 3), dtype=torch.float32, device=x.device)  # a 1x1 convolution as a centre-only 3x3
-            w3[:, :, 1, 1] = w.permute(0, 2, 3, 1).reshape(cin, 4 * cout)
-            dx = _conv_fwd(g, w3, torch.zeros(cin, device=x.device), False)
+            # a 1x1 convolution of G: weights (4*Cout, Cin), column ci of row q*Cout + co = w[ci][co][q]
+            dx = ops.conv1x1(g, w.permute(2, 3, 1, 0).reshape(4 * cout, cin))
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = ops.pix_gemm(x, 0, g, 1).view(cin, 2, 2, cout).permute(0, 3, 1, 2).contiguous()
             db = ops.channel_sum(g).view(4, cout).sum(0)

@@ -507,8 +507,11 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
 #pragma unroll
             for (int nt = 0; nt < WTN; ++nt) {
                 const int cbase = n0 + wn * (32 * WTN) + nt * 32;          // first GEMM column of this tile (wave-uniform)
-                const int co_base = CONVT ? cbase % Cout : cbase;
-                const int qd = CONVT ? cbase / Cout : 0;                    // (dy,dx) quadrant of a transposed conv
+                // pool == 2 on the transposed-conv kernel = a PLAIN 1x1 convolution (holo_conv1x1_f32): the same one-tap GEMM, its
+                // N columns stored as the channels of the input's own pixel instead of the four output quadrants
+                const bool plain = CONVT && pool == 2;
+                const int co_base = CONVT && !plain ? cbase % Cout : cbase;
+                const int qd = CONVT && !plain ? cbase / Cout : 0;          // (dy,dx) quadrant of a transposed conv
                 float v[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -528,7 +531,12 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
                 bool writer = inside;
                 size_t pix;                                                  // output pixel index (in pixels)
                 T* __restrict__ yimg;
-                if (CONVT) {
+                int cstride = Cout;                                          // channels per output pixel
+                if (CONVT && plain) {
+                    cstride = N;
+                    yimg = y + (size_t)img * H * W * N;
+                    pix = (size_t)Y * W + X;
+                } else if (CONVT) {
                     yimg = y + (size_t)img * (2 * H) * (2 * W) * Cout;
                     pix = (size_t)(2 * Y + (qd >> 1)) * (2 * W) + (2 * X + (qd & 1));
                 } else if (!pool) {
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((WTM * WTN > 4 && KC * sizeof(T) > 6
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (writer)
-                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(yimg) + pix * Cout + co_base + 8 * q + 4 * hsel) =
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(yimg) + pix * cstride + co_base + 8 * q + 4 * hsel) =
                                 make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                     continue;
                 }
@@ -901,6 +909,23 @@ static int convt2x2_entry(const T* x_nhwc, const T* w_packed, const float* bias,
 }  // namespace holo
 
 extern "C" {
+
+/* y (B,h,w,cout) = x (B,h,w,cin) . W (+ bias, ReLU): a plain 1x1 convolution on the transposed convolution's one-tap MFMA GEMM
+ * (the data gradient of ConvTranspose2d(k2,s2) over the space-to-depth gradient).  w_packed = holo_pack_convt2x2_weight_f32 of the
+ * (cin, cout/4, 2, 2) tensor T with T[k][c][dy][dx] = W[k][(2dy+dx)*cout/4 + c]. */
+int holo_conv1x1_f32(const float* x_nhwc, const float* w_packed, const float* bias, float* y_nhwc, int batch, int h, int w, int cin,
+                     int cout, int relu, void* stream) {
+    using namespace holo;
+    HOLO_REQUIRE(x_nhwc && w_packed && bias && y_nhwc, HOLO_ERR_ARG, "holo_conv1x1_f32: null pointer");
+    HOLO_REQUIRE(batch > 0 && h >= 1 && w >= 1, HOLO_ERR_ARG, "holo_conv1x1_f32: batch=%d h=%d w=%d", batch, h, w);
+    HOLO_REQUIRE(cin > 0 && cin % 16 == 0 && cout > 0 && cout % 64 == 0, HOLO_ERR_UNSUPPORTED,
+                 "holo_conv1x1_f32: Cin=%d must be a multiple of 16 and Cout=%d of 64", cin, cout);
+    HOLO_REQUIRE((long)h * w * (cin > cout ? cin : cout) < (1L << 30), HOLO_ERR_UNSUPPORTED,
+                 "holo_conv1x1_f32: one image must stay below 2^30 elements (32-bit byte offsets)");
+    hipStream_t s = as_stream(stream);
+    if (cout % 128 == 0) return launch_conv<2, 2, true, 16, float>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout / 4, relu, 2, s);
+    return launch_conv<4, 1, true, 16, float>(x_nhwc, w_packed, bias, y_nhwc, batch, h, w, cin, cout / 4, relu, 2, s);
+}
 
 size_t holo_conv3x3_packed_elems(int cout, int cin) { return (size_t)9 * (size_t)cin * (size_t)cout; }
 size_t holo_convt2x2_packed_elems(int cin, int cout) { return (size_t)4 * (size_t)cin * (size_t)cout; }

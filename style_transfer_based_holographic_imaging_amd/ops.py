@@ -622,6 +622,24 @@ def fold_reflect(dxp, h: int, w: int, border: int, batch: int = 0) -> torch.Tens
     return dx
 
 
+def conv1x1(x_nhwc, w_kn, bias=None, relu: bool = False) -> torch.Tensor:
+    """(B,h,w,cin) . w_kn (cin, cout) [+ bias] [ReLU] -> (B,h,w,cout), fp32, on the transposed convolution's one-tap MFMA GEMM."""
+    _req(x_nhwc, w_kn)
+    x_nhwc, w_kn = _f32c(x_nhwc), _f32c(w_kn.detach())
+    b, h, w, cin = x_nhwc.shape
+    cout = w_kn.shape[1]
+    assert w_kn.shape[0] == cin and cout % 4 == 0
+    # the packer's (Cin, Cout', 2, 2) layout with GEMM column (2dy+dx)*Cout' + c  (a re-layout of the weights: no arithmetic)
+    w_fake = w_kn.view(cin, 4, cout // 4).permute(0, 2, 1).reshape(cin, cout // 4, 2, 2).contiguous()
+    wp = pack_convt2x2(w_fake, torch.float32)
+    bias = torch.zeros(cout, dtype=torch.float32, device=x_nhwc.device) if bias is None else _f32c(bias)
+    y = torch.empty((b, h, w, cout), dtype=torch.float32, device=x_nhwc.device)
+    _launch("holo_conv1x1_f32", lambda: lib.holo_conv1x1_f32(x_nhwc.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr(), b, h, w, cin, cout,
+                                                             int(bool(relu)), _stream()),
+            flops=2.0 * b * h * w * cin * cout, nbytes=4.0 * (x_nhwc.numel() + y.numel()))
+    return y
+
+
 def space_to_depth2_relu(dy, y, relu: bool) -> torch.Tensor:
     """(B,2h,2w,c) gradient of a transposed-conv step's output -> (B,h,w,4c), masked by its ReLU."""
     _req(dy)

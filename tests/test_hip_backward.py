@@ -56,6 +56,22 @@ def test_conv_step(ag, dev, b, h, w, cin, cout, relu, pool):
     assert rel_err(bd.grad.cpu(), br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,relu", [(2, 5, 7, 64, 64, False), (1, 9, 20, 256, 128, True), (1, 3, 3, 1024, 256, False),
+                                                 (3, 17, 16, 512, 192, True)])
+def test_conv1x1(dev, b, h, w, cin, cout, relu):
+    """the plain 1x1 convolution on the transposed convolution's one-tap GEMM (64- and 128-wide column tiles, partial pixel tiles)"""
+    from style_transfer_based_holographic_imaging_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(b, h, w, cin, generator=g)
+    wt = torch.randn(cin, cout, generator=g) / math.sqrt(cin)
+    bias = torch.randn(cout, generator=g)
+    want = torch.einsum("bhwk,kn->bhwn", x.double(), wt.double()) + bias.double()
+    if relu:
+        want = want.clamp_min(0)
+    got = ops.conv1x1(x.to(dev), wt.to(dev), bias.to(dev), relu)
+    assert got.shape == want.shape and rel_err(got.cpu(), want) < 2e-6
+
+
 @pytest.mark.parametrize("b,h,w,mc,nc", [(2, 11, 32, 64, 64), (1, 40, 64, 128, 64), (3, 7, 32, 64, 192)])
 def test_pix_gemm_kernels_agree(dev, monkeypatch, b, h, w, mc, nc):
     """the LDS-staged 9-tap kernel against the operands-from-global one (HOLO_PIX_GEMM_DIRECT=1) and a float64 einsum"""

@@ -40,6 +40,12 @@ done
 python bench.py --batch 5 --size 128 --cpu-sample 0 --steps 200 --warmup 20 --no-events 2>/dev/null > $O/${R}_bench_b5_auto_noevents.json    # the step without a HIP event pair around each of its 45 launches
 python bench.py --batch 1 --size 256 --cpu-sample 0 --steps 200 --warmup 20 --no-events 2>/dev/null > $O/${R}_bench_b1_s256_noevents.json
 python scripts/per_layer.py --batch 5 --size 128 --reps 20 > $O/${R}_layers_b5.txt 2>&1
+# the training step: HIP kernels against stock PyTorch-ROCm autograd, and its kernel statistics
+python scripts/train_step.py --batch 16 --size 256 --steps 5 2>/dev/null | tail -1 > $O/${R}_train_step.json
+python tests/diagnostics/torch_rocm_train_baseline.py --batch 16 --size 256 --steps 5 2>/dev/null | tail -1 > $O/${R}_torch_rocm_train_baseline.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/${R}_prof_train -o train --output-format csv -- python3 /root/repo/scripts/train_step.py --batch 16 --size 256 --steps 3 > $O/${R}_prof_train.json 2> $O/${R}_prof_train.err
+cd /root/repo
 fi
 R_=$R python - <<'PY'
 import json,glob,os

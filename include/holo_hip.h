@@ -121,6 +121,17 @@ int holo_channel_mean_std_f32(const float* x_nhwc, float* mean, float* std, int 
 int holo_adain_apply_f32(const float* x_nhwc, const float* mean, const float* std,
                          const float* style_mean, const float* style_std, long style_batch_stride,
                          float alpha, float* y_nhwc, int batch, int hw, int c, void* stream);
+/* calc_mean_std + AdaIN (function.py:4-12 then net.py:240-246) in ONE launch: mean / std (B,c) written as by
+ * holo_channel_mean_std_* (the distance head reads them), y as by holo_adain_apply_*; bit-identical to the two calls */
+int holo_adain_fused_f32(const float* x_nhwc, float* mean, float* std, const float* style_mean, const float* style_std,
+                         long style_batch_stride, float alpha, float* y_nhwc, int batch, int hw, int c, float eps,
+                         void* stream);
+int holo_adain_fused_bf16(const uint16_t* x_nhwc, float* mean, float* std, const float* style_mean, const float* style_std,
+                          long style_batch_stride, float alpha, uint16_t* y_nhwc, int batch, int hw, int c, float eps,
+                          void* stream);
+int holo_adain_fused_f32s(const void* x_nhwc, float* mean, float* std, const float* style_mean, const float* style_std,
+                          long style_batch_stride, float alpha, void* y_nhwc, int batch, int hw, int c, float eps,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Distance head (net.py:288-308)

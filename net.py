@@ -187,8 +187,7 @@ class Net(nn.Module):
                 raise RuntimeError(f"multiple-style vector holds {half} styles for a batch of {b}")
         else:                          # single style broadcast over the batch
             style_mean, style_std = style_feats[:1].reshape(1, c), style_feats[1:].reshape(1, c)
-        mean, std = ops.channel_mean_std(feat_nhwc)
-        t = ops.adain_apply(feat_nhwc, mean, std, style_mean, style_std, float(alpha))
+        t, mean, std = ops.adain_fused(feat_nhwc, style_mean, style_std, float(alpha))   # statistics + AdaIN, one launch
         g_t = self.decoder.run_nhwc(t)                           # (B,2,S,S) planes
         g_t_phase = g_t[:, 1:]
         g_t = g_t[:, :1]

@@ -45,6 +45,9 @@ SIGNATURES = {
     "holo_conv_last_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_channel_mean_std_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "holo_adain_apply_f32": (_i, [_p, _p, _p, _p, _p, _l, _f, _p, _i, _i, _i, _p]),
+    "holo_adain_fused_f32": (_i, [_p, _p, _p, _p, _p, _l, _f, _p, _i, _i, _i, _f, _p]),
+    "holo_adain_fused_bf16": (_i, [_p, _p, _p, _p, _p, _l, _f, _p, _i, _i, _i, _f, _p]),
+    "holo_adain_fused_f32s": (_i, [_p, _p, _p, _p, _p, _l, _f, _p, _i, _i, _i, _f, _p]),
     "holo_linear_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_rownorm_relu_f32": (_i, [_p, _p, _i, _i, _f, _p]),
     "holo_linear1_sigmoid_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),

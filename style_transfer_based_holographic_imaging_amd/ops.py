@@ -370,6 +370,25 @@ def adain_apply(x_nhwc, mean, std, style_mean, style_std, alpha: float = 1.0):
     return y
 
 
+def adain_fused(x_nhwc, style_mean, style_std, alpha: float = 1.0, eps: float = 1e-5):
+    """channel_mean_std + adain_apply in one launch: returns (y, mean, std), bit-identical to the two calls."""
+    _req(x_nhwc, style_mean, style_std)
+    b, h, w, c = x_nhwc.shape
+    x_nhwc = _actc(x_nhwc)
+    style_mean = _f32c(style_mean.reshape(-1, c))
+    style_std = _f32c(style_std.reshape(-1, c))
+    assert style_mean.shape == style_std.shape and style_mean.shape[0] in (1, b)
+    stride = 0 if style_mean.shape[0] == 1 and b != 1 else c
+    y = torch.empty_like(x_nhwc)
+    mean = torch.empty((b, c), dtype=torch.float32, device=x_nhwc.device)
+    std = torch.empty_like(mean)
+    name = "holo_adain_fused_" + _sfx(x_nhwc)
+    _launch(name, lambda: getattr(lib, name)(x_nhwc.data_ptr(), mean.data_ptr(), std.data_ptr(), style_mean.data_ptr(), style_std.data_ptr(),
+                                             stride, float(alpha), y.data_ptr(), b, h * w, c, float(eps), _stream()),
+            nbytes=3.0 * x_nhwc.element_size() * b * h * w * c)
+    return y, mean, std
+
+
 # ---------------------------------------------------------------------------------------------
 # distance head
 # ---------------------------------------------------------------------------------------------

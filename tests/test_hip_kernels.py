@@ -112,12 +112,21 @@ def test_mean_std_and_adain(ops, dev, b, c, h, w):
         xm, xs = ops.channel_mean_std(ops.to_nhwc(x.to(dev)))
         y = ops.adain_apply(ops.to_nhwc(x.to(dev)), xm, xs, sv[:1].to(dev), sv[1:].to(dev), alpha)
         assert rel_err(ops.as_nchw_view(y).cpu(), ref) < 2e-6
+        # the one-launch form (statistics + AdaIN): the same bits, for fp32 and bf16 activations
+        for dt in (torch.float32, torch.bfloat16):
+            xa = ops.to_nhwc(x.to(dev)).to(dt).contiguous()
+            m2, s2 = ops.channel_mean_std(xa)
+            y2 = ops.adain_apply(xa, m2, s2, sv[:1].to(dev), sv[1:].to(dev), alpha)
+            yf, mf, sf = ops.adain_fused(xa, sv[:1].to(dev), sv[1:].to(dev), alpha)
+            assert torch.equal(yf, y2) and torch.equal(mf, m2) and torch.equal(sf, s2)
     multi = torch.cat([torch.randn(b, c, 1, 1, generator=g), torch.rand(b, c, 1, 1, generator=g) + 0.2], 0)
     if b > 1:
         ref = orc.adain_with_style_vector(x, multi, 1.0)
         xm, xs = ops.channel_mean_std(ops.to_nhwc(x.to(dev)))
         y = ops.adain_apply(ops.to_nhwc(x.to(dev)), xm, xs, multi[:b].to(dev), multi[b:].to(dev), 1.0)
         assert rel_err(ops.as_nchw_view(y).cpu(), ref) < 2e-6
+        yf, mf, sf = ops.adain_fused(ops.to_nhwc(x.to(dev)), multi[:b].to(dev), multi[b:].to(dev), 1.0)
+        assert torch.equal(yf, y) and torch.equal(mf, xm) and torch.equal(sf, xs)
 
 
 @pytest.mark.parametrize("b", [1, 3, 8, 19])

@@ -18,6 +18,8 @@ packers and the scalar MSE reductions (``nn.MSELoss``, as in the reference) stay
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
@@ -25,15 +27,57 @@ from . import ops
 WINO_MIN_ITEMS = 128
 
 
-def _conv_fwd(x_nhwc, w_oihw, bias, relu, allow_wino=True):
-    """forward 3x3 convolution (reflection padding) of an NHWC fp32 tensor with an OIHW weight, on the Winograd kernel where the
-    layer fills the chip, else the implicit-GEMM kernel"""
-    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+# packed forms of a parameter, kept until the parameter is written again (tensor._version: every in-place optimizer update bumps
+# it).  A step uses each decoder weight in two passes and each frozen encoder weight in three, forward and flipped: packing once
+# per version takes 54 of a step's 72 packing launches (and the flip / transpose copies in front of them) away.
+_PACKED = {}      # id(parameter) -> (weak reference to it, {kind: (version, packed tensor)}); dropped when the parameter dies
+
+
+def _packed(weight, kind):
+    """kind: 'wino' | 'direct' (forward convolution), 'wino_t' | 'direct_t' (the data gradient's flipped, transposed weights)"""
+    key = id(weight)
+    slot = _PACKED.get(key)
+    if slot is None or slot[0]() is not weight:         # a new object (an id can be reused once its tensor is gone)
+        slot = _PACKED[key] = (weakref.ref(weight, lambda _, k=key: _PACKED.pop(k, None)), {})
+    hit = slot[1].get(kind)
+    if hit is not None and hit[0] == weight._version:
+        return hit[1]
+    w = weight.detach()
+    if kind.endswith("_t"):
+        w = w.flip(2, 3).transpose(0, 1).contiguous()                                     # (Cin, Cout, 3, 3): full correlation
+    packed = ops.pack_conv3x3_wino(w) if kind.startswith("wino") else ops.pack_conv3x3(w, torch.float32)
+    slot[1][kind] = (weight._version, packed)
+    return packed
+
+
+def forget_packed_weights():
+    """drop every cached packed weight (``HoloSequential.invalidate_packed_weights`` calls this: a write through ``.data`` changes
+    a parameter without bumping its version)"""
+    _PACKED.clear()
+
+
+def _conv_fwd(x_nhwc, weight, bias, relu, transposed=False):
+    """forward 3x3 convolution (reflection padding) of an NHWC fp32 tensor with the OIHW parameter ``weight`` (``transposed``: with
+    its flipped, transposed form — the data gradient), on the Winograd kernel where the layer fills the chip, else the
+    implicit-GEMM kernel"""
+    cout, cin = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
     b, h, w, _ = x_nhwc.shape
     items = b * ((h + 31) // 32) * ((w + 15) // 16) * (cout // 32)
-    if allow_wino and cin >= 32 and cin % 16 == 0 and cout % 32 == 0 and items >= WINO_MIN_ITEMS:
-        return ops.conv3x3_wino(x_nhwc, ops.pack_conv3x3_wino(w_oihw), bias, cout, relu, False)
-    return ops.conv3x3(x_nhwc, ops.pack_conv3x3(w_oihw, torch.float32), bias, cout, relu, False)
+    sfx = "_t" if transposed else ""
+    if cin >= 32 and cin % 16 == 0 and cout % 32 == 0 and items >= WINO_MIN_ITEMS:
+        return ops.conv3x3_wino(x_nhwc, _packed(weight, "wino" + sfx), bias, cout, relu, False)
+    return ops.conv3x3(x_nhwc, _packed(weight, "direct" + sfx), bias, cout, relu, False)
+
+
+_ZEROS = {}
+
+
+def _zero_bias(n, device):
+    key = (n, str(device))
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return z
 
 
 class ConvStep(torch.autograd.Function):
@@ -41,16 +85,19 @@ class ConvStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, pool):
-        w = weight.detach()
-        y_act = _conv_fwd(x.detach(), w, bias.detach().float().contiguous(), relu)
+        y_act = _conv_fwd(x.detach(), weight, bias.detach().float().contiguous(), relu)
         y = ops.maxpool2x2(y_act) if pool else y_act
         ctx.relu, ctx.pool = relu, pool
-        ctx.save_for_backward(x.detach(), w, y_act if (relu or pool) else None, y if pool else None)
+        ctx.weight, ctx.weight_version = weight, weight._version     # the parameter itself: packed forms are cached per version
+        ctx.save_for_backward(x.detach(), y_act if (relu or pool) else None, y if pool else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y_act, y_pool = ctx.saved_tensors
+        x, y_act, y_pool = ctx.saved_tensors
+        w = ctx.weight
+        if w._version != ctx.weight_version:
+            raise RuntimeError("a convolution weight needed for the backward pass was modified in place after the forward pass")
         b, h, wd, cin = x.shape
         cout = w.shape[0]
         if y_act is None:
@@ -68,8 +115,7 @@ class ConvStep(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if cin % 64 != 0:
                 raise NotImplementedError(f"data gradient of a {cin} -> {cout} convolution: the forward kernels need Cout % 64 == 0")
-            wd_t = w.flip(2, 3).transpose(0, 1).contiguous()                               # (Cin, Cout, 3, 3): full correlation
-            dxp = _conv_fwd(dap, wd_t, torch.zeros(cin, device=x.device), False)          # same shape as dap, Cin channels
+            dxp = _conv_fwd(dap, w, _zero_bias(cin, x.device), False, transposed=True)    # same shape as dap, Cin channels
             dx = ops.fold_reflect(dxp, h, wd, 2, batch=b if tall else 0)
         if need_w:
             dw = ops.pix_gemm(dap, 2, x, 9).view(cout, cin, 3, 3)

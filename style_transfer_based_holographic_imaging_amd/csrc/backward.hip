@@ -802,7 +802,7 @@ static inline bool pix_gemm_force_direct() {
     return e && e[0] == '1';
 }
 static inline bool pix_gemm_lds(int w, int mc, int nc, int taps) { return taps == 9 && w % kPgChunk == 0 && mc % 64 == 0 && nc % 64 == 0; }
-// the LDS-staged kernel's units: (image, 32-pixel strip, row group); about four blocks per CU over the grid
+// the LDS-staged kernel's units: (image, 32-pixel strip, row group); about two blocks per CU over the grid
 struct PixGemmLdsPlan {
     int rows_per_unit, groups;
     long units;
@@ -810,7 +810,8 @@ struct PixGemmLdsPlan {
 static PixGemmLdsPlan pix_gemm_lds_plan(int batch, int h, int w, int mc, int nc) {
     const long tiles = (long)(mc / 64) * (nc / 64);
     const long strips = (long)batch * (w / kPgChunk);
-    long groups = (1024 + tiles * strips - 1) / (tiles * strips);
+    const long target = 2L * device_cus();          // one resident round of blocks (two per CU): 512 measured ahead of 1024 and 2048
+    long groups = (target + tiles * strips - 1) / (tiles * strips);
     if (groups > h / 2) groups = h / 2;
     if (groups < 1) groups = 1;
     PixGemmLdsPlan pl;

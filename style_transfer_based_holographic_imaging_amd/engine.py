@@ -250,6 +250,8 @@ class HoloSequential(nn.Sequential):
         plan = getattr(self, "_holo_plan", None)
         if plan is not None:
             plan.invalidate()
+        from . import autograd as _ag       # the training path's per-version cache (writes through ``.data`` do not bump a version)
+        _ag.forget_packed_weights()
         return self
 
     def load_state_dict(self, *args, **kwargs):

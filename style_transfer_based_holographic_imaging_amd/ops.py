@@ -742,7 +742,7 @@ def conv_first_dgrad(da_nhwc, w0, w1) -> torch.Tensor:
     return din
 
 
-WIDE_STATS_MIN_HW = 16384
+WIDE_STATS_MIN_HW = 2048
 
 
 def channel_mean_std_wide(x_nhwc: torch.Tensor, eps: float = 1e-5):

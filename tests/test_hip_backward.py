@@ -271,3 +271,43 @@ def test_gradients_at_benchmark_size_against_aten_on_the_device(dev):
     worst = max(rel_err(params[k].grad.cpu(), want[k].cpu()) for k in want)
     print(f"worst relative gradient deviation from aten at 4 x 256^2: {worst:.2e}")
     assert worst < 3e-4
+
+
+@pytest.mark.parametrize("b,h,w", [(3, 40, 56), (1, 24, 72)])
+def test_gradients_at_small_rectangular_sizes(dev, b, h, w):
+    """rectangular holograms whose maps are no whole 32-pixel strips or tiles (56 -> 28 -> 14 -> 7 wide: the operands-from-global
+    weight-gradient kernel, partial Winograd tiles), a batch in the tall layout and a single hologram: the whole objective against
+    torch.autograd over the oracle on the CPU (fp32 against fp32, 2e-4).  Sides are multiples of 8, as the objective itself
+    requires (net.py:192: the style loss asserts equal map sizes)."""
+    import os
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import holo_oracle as orc
+    from hip_helpers import build_network
+    from style_transfer_based_holographic_imaging_amd import synth
+    network, _ = build_network(0)
+    params = dict(("decoder." + k, p) for k, p in network.decoder.named_parameters())
+    params.update(("distance_g." + k, p) for k, p in network.distance_g.named_parameters())
+    for p in params.values():
+        p.requires_grad_(True)
+    g = torch.Generator().manual_seed(h * w)
+    content = torch.rand(b, 1, h, w, generator=g) * 0.8 + 0.1
+    style = torch.rand(b, 1, h, w, generator=g) * 0.8 + 0.1
+
+    def objective(out):
+        lc, ls, g_t, g_ph, s_re, d_c, d_s = out
+        return lc + 10.0 * ls + s_re.pow(2).mean() + g_ph.pow(2).mean() + (g_t - 0.3).pow(2).mean() + (d_c - 0.5).pow(2).sum() + (d_s - 0.2).pow(2).sum()
+
+    obj = objective(network(content.to(dev), style.to(dev), 0.7, True, True))
+    obj.backward()
+    vgg_sd, dec_sd, dist_sd = synth.synthetic_state_dicts(0)
+    dec = {k: v.clone().requires_grad_() for k, v in dec_sd.items()}
+    dist = {k: v.clone().requires_grad_() for k, v in dist_sd.items()}
+    ref = objective(orc.net_forward(content, style, vgg_sd, dec, dist, 0.7, True, True))
+    ref.backward()
+    assert abs(float(obj.detach()) - float(ref.detach())) < 1e-4 * abs(float(ref.detach()))
+    want = {"decoder." + k: v.grad for k, v in dec.items()}
+    want.update({"distance_g." + k: v.grad for k, v in dist.items()})
+    worst = max(rel_err(params[k].grad.cpu(), want[k]) for k in want)
+    assert worst < 2e-4, worst

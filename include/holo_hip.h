@@ -334,6 +334,9 @@ int holo_mean_std_bwd_f32(const float* x_nhwc, const float* mean, const float* s
  * output), sigmoid */
 int holo_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int batch, int fin,
                         int fout, void* stream);
+/* nn.Dropout in training mode (net.py:298-304, on each Linear's output): y = x * keep * scale with the drawn 0/1 mask `keep` and
+ * scale = 1/(1-p); the same call carries the gradient back */
+int holo_mask_scale_f32(const float* x, const float* keep, float scale, float* y, long n, void* stream);
 int holo_rownorm_relu_bwd_f32(const float* z, const float* dy, float* dz, int batch, int f, float eps, void* stream);
 int holo_sigmoid_bwd_f32(const float* y, const float* dy, float* dz, int n, void* stream);
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "holo_nchw_to_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p]),
     # backward pass (ABI 5)
     "holo_maxpool2x2_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "holo_mask_scale_f32": (_i, [_p, _p, _f, _p, _l, _p]),
     "holo_conv1x1_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "holo_relu_pool_bwd_pad_workspace_bytes": (_z, [_i]),
     "holo_relu_pool_bwd_pad_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _z, _p]),

@@ -206,39 +206,44 @@ class MeanStd(torch.autograd.Function):
 
 
 class DistanceHead(torch.autograd.Function):
-    """Distance_G.forward (net.py:288-308) on (mean, std) of shape (B,512): three Linear -> per-row norm -> ReLU, then
-    sigmoid(Linear).  Gradients for the eight parameters and the two inputs."""
+    """Distance_G.forward (net.py:288-308) on (mean, std) of shape (B,512): three Linear [-> Dropout] -> per-row norm -> ReLU, then
+    sigmoid(Linear).  Gradients for the eight parameters and the two inputs.  ``keep``: None (eval mode: Dropout is the identity)
+    or the three drawn 0/1 masks of training mode, applied to each Linear's output with ``scale`` = 1/(1-p) (net.py:298-304)."""
 
     @staticmethod
-    def forward(ctx, mean, std, w1, b1, w2, b2, w3, b3, wo, bo):
+    def forward(ctx, mean, std, w1, b1, w2, b2, w3, b3, wo, bo, keep=None, scale=1.0):
         x0 = torch.cat([mean.detach(), std.detach()], 1).float().contiguous()
         ps = [t.detach().float().contiguous() for t in (w1, b1, w2, b2, w3, b3, wo, bo)]
-        z1 = ops.linear(x0, ps[0], ps[1])
+        drop = (lambda z, k: ops.mask_scale(z, keep[k], scale)) if keep is not None else (lambda z, k: z)
+        z1 = drop(ops.linear(x0, ps[0], ps[1]), 0)
         a1 = ops.rownorm_relu(z1)
-        z2 = ops.linear(a1, ps[2], ps[3])
+        z2 = drop(ops.linear(a1, ps[2], ps[3]), 1)
         a2 = ops.rownorm_relu(z2)
-        z3 = ops.linear(a2, ps[4], ps[5])
+        z3 = drop(ops.linear(a2, ps[4], ps[5]), 2)
         a3 = ops.rownorm_relu(z3)
         y = ops.linear1_sigmoid(a3, ps[6], ps[7])
+        ctx.keep, ctx.scale = keep, scale
         ctx.save_for_backward(x0, z1, a1, z2, a2, z3, a3, y, ps[0], ps[2], ps[4], ps[6])
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x0, z1, a1, z2, a2, z3, a3, y, w1, w2, w3, wo = ctx.saved_tensors
+        keep, scale = ctx.keep, ctx.scale
+        undrop = (lambda dz, k: ops.mask_scale(dz, keep[k], scale)) if keep is not None else (lambda dz, k: dz)
         dz4 = ops.sigmoid_bwd(y, dy.contiguous())
         da3, dwo, dbo = ops.linear_bwd(dz4, a3, wo)
-        dz3 = ops.rownorm_relu_bwd(z3, da3)
+        dz3 = undrop(ops.rownorm_relu_bwd(z3, da3), 2)
         da2, dw3, db3 = ops.linear_bwd(dz3, a2, w3)
-        dz2 = ops.rownorm_relu_bwd(z2, da2)
+        dz2 = undrop(ops.rownorm_relu_bwd(z2, da2), 1)
         da1, dw2, db2 = ops.linear_bwd(dz2, a1, w2)
-        dz1 = ops.rownorm_relu_bwd(z1, da1)
+        dz1 = undrop(ops.rownorm_relu_bwd(z1, da1), 0)
         need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dx0, dw1, db1 = ops.linear_bwd(dz1, x0, w1, need_dx=need_in)
         c = x0.shape[1] // 2
         dmean = dx0[:, :c].contiguous() if need_in else None
         dstd = dx0[:, c:].contiguous() if need_in else None
-        return dmean, dstd, dw1, db1, dw2, db2, dw3, db3, dwo, dbo
+        return dmean, dstd, dw1, db1, dw2, db2, dw3, db3, dwo, dbo, None, None
 
 
 def needs_graph(x, *modules):

@@ -762,6 +762,14 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
     if (i < n) dz[i] = dy[i] * y[i] * (1.0f - y[i]);
 }
 
+// nn.Dropout in training mode (net.py:298-304: on each Linear's output, before the row norm): y = x * keep * scale, keep in {0, 1};
+// the same kernel carries the gradient back
+__global__ __launch_bounds__(256) void mask_scale_kernel(const float* __restrict__ x, const float* __restrict__ keep, float scale,
+                                                         float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = x[i] * keep[i] * scale;
+}
+
 static inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
 constexpr int kFoldKeep = 64, kFoldBy = 32;
@@ -1063,6 +1071,13 @@ int holo_sigmoid_bwd_f32(const float* y, const float* dy, float* dz, int n, void
     HOLO_REQUIRE(y && dy && dz && n > 0, HOLO_ERR_ARG, "holo_sigmoid_bwd_f32: bad argument");
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), y, dy, dz, n);
     return check_launch("holo_sigmoid_bwd_f32");
+}
+
+/* y = x * keep * scale elementwise: nn.Dropout's training-mode forward (keep = the drawn 0/1 mask, scale = 1/(1-p)) and backward */
+int holo_mask_scale_f32(const float* x, const float* keep, float scale, float* y, long n, void* stream) {
+    HOLO_REQUIRE(x && keep && y && n > 0, HOLO_ERR_ARG, "holo_mask_scale_f32: bad argument");
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), x, keep, scale, y, n);
+    return check_launch("holo_mask_scale_f32");
 }
 
 }  // extern "C"

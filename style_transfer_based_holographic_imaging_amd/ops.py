@@ -772,6 +772,17 @@ def mean_std_bwd(x_nhwc, mean, std, dmean, dstd) -> torch.Tensor:
     return dx
 
 
+def mask_scale(x, keep, scale: float) -> torch.Tensor:
+    """x * keep * scale (training-mode Dropout and its gradient), fp32."""
+    _req(x, keep)
+    x, keep = _f32c(x), _f32c(keep)
+    assert x.shape == keep.shape
+    y = torch.empty_like(x)
+    _launch("holo_mask_scale_f32", lambda: lib.holo_mask_scale_f32(x.data_ptr(), keep.data_ptr(), float(scale), y.data_ptr(), x.numel(), _stream()),
+            nbytes=12.0 * x.numel())
+    return y
+
+
 def linear_bwd(dy, x, w, need_dx=True, need_dw=True):
     _req(dy, x, w)
     dy, x, w = _f32c(dy), _f32c(x), _f32c(w.detach())

@@ -199,6 +199,50 @@ def test_mean_std_and_distance_head(ag, dev):
         assert rel_err(v.grad.cpu(), ps[k].grad) < 5e-5, k
 
 
+def test_distance_head_training_mode_dropout(ag, dev):
+    """Distance_G in training mode (net.py:298-304: Dropout on each Linear's output, before the row norm): given the drawn masks,
+    values and all gradients against the same arithmetic in torch; and the module itself draws masks from torch's generator."""
+    import net
+    g = torch.Generator().manual_seed(21)
+    torch.manual_seed(5)
+    head = net.Distance_G()
+    for p in head.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    b = 6
+    mean, std = torch.randn(b, 512, generator=g), torch.rand(b, 512, generator=g) + 0.3
+    keep = [(torch.rand(b, n, generator=g) < 0.5).float() for n in (1024, 1024, 512)]
+    ps = {k: v.detach().clone().requires_grad_() for k, v in head.state_dict().items()}
+    mr, sr = mean.clone().requires_grad_(), std.clone().requires_grad_()
+    h = torch.cat([mr, sr], 1)
+    for name, kp in zip(("l1", "l2", "l3"), keep):
+        z = F.linear(h, ps[f"{name}.weight"], ps[f"{name}.bias"]) * kp * 2.0
+        z = (z - z.mean(1, keepdim=True)) / torch.sqrt(z.var(1, unbiased=False, keepdim=True) + 1e-5)
+        h = F.relu(z)
+    yr = torch.sigmoid(F.linear(h, ps["out.weight"], ps["out.bias"]))
+    uy = torch.randn(b, 1, generator=g)
+    (yr * uy).sum().backward()
+    head = head.to(dev)
+    md, sd_ = mean.to(dev).requires_grad_(), std.to(dev).requires_grad_()
+    yd = ag.DistanceHead.apply(md, sd_, head.l1.weight, head.l1.bias, head.l2.weight, head.l2.bias, head.l3.weight, head.l3.bias,
+                               head.out.weight, head.out.bias, [k.to(dev) for k in keep], 2.0)
+    assert rel_err(yd.detach().cpu(), yr.detach()) < 1e-5
+    (yd * uy.to(dev)).sum().backward()
+    assert rel_err(md.grad.cpu(), mr.grad) < 5e-5 and rel_err(sd_.grad.cpu(), sr.grad) < 5e-5
+    for k, v in head.named_parameters():
+        assert rel_err(v.grad.cpu(), ps[k].grad) < 5e-5, k
+    # the module: eval mode is deterministic, training mode draws masks (seeded: reproducible; differs from eval)
+    m4, s4 = mean.to(dev).view(b, 512, 1, 1), std.to(dev).view(b, 512, 1, 1)
+    with torch.no_grad():
+        e0 = head.eval()((m4, s4))
+        head.train()
+        torch.manual_seed(1)
+        t0 = head((m4, s4))
+        torch.manual_seed(1)
+        t1 = head((m4, s4))
+        head.eval()
+    assert torch.equal(t0, t1) and not torch.equal(t0, e0) and t0.shape == e0.shape == (b, 1)
+
+
 def test_net_forward_gradients_against_reference_golden(golden, dev):
     """The whole training objective on the HIP kernels: ``Net.forward`` (all seven results) -> the scalar objective of the golden
     recipe -> ``backward()``: gradients of every decoder and distance-head parameter against the REFERENCE's own

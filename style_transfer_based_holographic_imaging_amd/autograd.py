@@ -6,12 +6,13 @@ forward AND backward are C-ABI calls (include/holo_hip.h, ABI 5; csrc/backward.h
 
   conv step      ReflPad + Conv3x3 [+ ReLU] [+ MaxPool ceil]
                  dX = fold_reflect( forward_conv( pad2(route/mask(dY)), flip(W)^T ) )      the data gradient runs on the FORWARD kernels
-                 dW = pix_gemm(pad2(...), X, 9 taps),  db = channel_sum
+                 dW = pix_gemm(pad2(...), X, 9 taps),  db summed by the mask / pad pass.  A batch's pad2(...) is ONE tall image
+                 (neighbours share their zero rows), so the convolution rounds the batch, not each image, up to whole tiles
   convt step     ConvTranspose k2s2 [+ ReLU]:  G = space_to_depth(mask(dY));  dX = 1x1 conv of G (the transposed convolution's own
                  one-tap MFMA GEMM, stored plainly);  dW = pix_gemm(X, G, 1 tap)
   first / last   the skinny layers: VALU kernels (first: data gradient only, the encoder is frozen, net.py:167-170)
   mean_std       calc_mean_std (function.py:4-12)
-  distance head  Linear / per-row norm + ReLU / sigmoid, layer by layer (net.py:288-308)
+  distance head  Linear [/ Dropout in training mode] / per-row norm + ReLU / sigmoid, layer by layer (net.py:288-308)
 
 fp32 only.  View ops (permute, reshape, slicing), ``torch.cat`` of the two statistics, the weight flips / transposes feeding the
 packers and the scalar MSE reductions (``nn.MSELoss``, as in the reference) stay torch's own: plumbing, no arithmetic of the path.

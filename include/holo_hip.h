@@ -282,17 +282,20 @@ int holo_maxpool2x2_f32(const float* x_nhwc, float* y_nhwc, int batch, int h, in
  * the layer's post-ReLU, pre-pool output */
 /* pitch_rows: rows from one image's block of out_padded to the next; 0 = h + 2*border (separate blocks).  Less (down to
  * h + border) = the TALL layout: neighbouring images share their zero rows, and the batch is one image of
- * (B-1)*pitch_rows + h + 2*border rows for the convolution that follows (no per-image round-up to whole tiles) */
+ * (B-1)*pitch_rows + h + 2*border rows for the convolution that follows (no per-image round-up to whole tiles).
+ * per_row > 1 (needs border >= 1): a MOSAIC — that many images side by side as well, w + border columns apart (shared zero
+ * columns); image n at cell (n / per_row, n % per_row), cells past the batch zero; out_padded is then
+ * (ceil(B/per_row)-1)*pitch_rows + h + 2*border rows of (per_row-1)*(w+border) + w + 2*border pixels.  0 / 1: one image per row */
 /* dbias (c) or NULL: the bias gradient = sum of out_padded over its pixels, accumulated in the same pass (float64 partial sums,
  * fixed order); needs a workspace of holo_relu_pool_bwd_pad_workspace_bytes(c) */
 size_t holo_relu_pool_bwd_pad_workspace_bytes(int c);
 int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float* y_pool, float* out_padded, int batch,
-                               int h, int w, int c, int relu, int border, int pitch_rows, float* dbias, void* workspace,
-                               size_t workspace_bytes, void* stream);
+                               int h, int w, int c, int relu, int border, int pitch_rows, int per_row, float* dbias,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* adjoint of ReflectionPad2d(1): dx (B,h,w,c) = interior of dxp (B,h+2*border,w+2*border,c) plus its pad ring (padded row -1
- * onto row 1, row h onto row h-2, likewise columns); border = 1 or 2; pitch_rows as above (0 = h + 2*border) */
+ * onto row 1, row h onto row h-2, likewise columns); border = 1 or 2; pitch_rows / per_row as above (0 = separate blocks) */
 int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, int pitch_rows,
-                          void* stream);
+                          int per_row, void* stream);
 /* y (B,h,w,cout) = x (B,h,w,cin) . W[cin][cout] + bias [ReLU]: a plain 1x1 convolution on the one-tap MFMA GEMM of the transposed
  * convolution (net.py:46-65 backward: the data gradient of ConvTranspose2d(k2,s2) is a 1x1 convolution of the space-to-depth
  * gradient).  w_packed = holo_pack_convt2x2_weight_f32 of the (cin, cout/4, 2, 2) tensor T[k][c][dy][dx] = W[k][(2dy+dx)*cout/4 + c];
@@ -308,10 +311,10 @@ int holo_channel_sum_f32(const float* x, float* out, long rows, int c, void* wor
 /* out[m][n][tap] = sum over the B*h*w pixels of P[pixel][m] * Q[reflect(pixel + tap)][n]: weight gradients as a GEMM whose K runs
  * over pixels (v_mfma_f32_32x32x2_f32, deterministic).  P (B,h+2*p_border,w+2*p_border,mc) read at its interior, Q (B,h,w,nc),
  * taps = 9 (tap = ky*3+kx, reflected neighbour: out is the OIHW gradient for m = Cout, n = Cin) or 1; mc, nc % 32 == 0;
- * p_pitch_rows: rows between the images' blocks of P (0 = h + 2*p_border; the tall layout of holo_relu_pool_bwd_pad_f32) */
+ * p_pitch_rows / p_per_row: the layout of P as written by holo_relu_pool_bwd_pad_f32 (0 / 0 = separate blocks) */
 size_t holo_pix_gemm_workspace_bytes(int batch, int h, int w, int mc, int nc, int taps);
-int holo_pix_gemm_f32(const float* p, int p_border, int p_pitch_rows, const float* q, float* out, int batch, int h, int w,
-                      int mc, int nc, int taps, void* workspace, size_t workspace_bytes, void* stream);
+int holo_pix_gemm_f32(const float* p, int p_border, int p_pitch_rows, int p_per_row, const float* q, float* out, int batch,
+                      int h, int w, int mc, int nc, int taps, void* workspace, size_t workspace_bytes, void* stream);
 /* decoder[36:38] (net.py:72-73) backward: dy (B,2,h,w) planes, x (B,h,w,64) the layer's input; dxp (B,h+2,w+2,64) = data gradient
  * on the padded domain (fold with holo_fold_reflect_f32, border 1) or NULL; dw (2,64,3,3) + db (2) or NULL */
 size_t holo_conv_last_bwd_workspace_bytes(int batch, int h, int w);

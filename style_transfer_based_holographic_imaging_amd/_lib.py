@@ -85,13 +85,13 @@ SIGNATURES = {
     "holo_mask_scale_f32": (_i, [_p, _p, _f, _p, _l, _p]),
     "holo_conv1x1_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "holo_relu_pool_bwd_pad_workspace_bytes": (_z, [_i]),
-    "holo_relu_pool_bwd_pad_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
-    "holo_fold_reflect_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "holo_relu_pool_bwd_pad_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
+    "holo_fold_reflect_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "holo_space_to_depth2_relu_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "holo_channel_sum_workspace_bytes": (_z, [_l, _i]),
     "holo_channel_sum_f32": (_i, [_p, _p, _l, _i, _p, _z, _p]),
     "holo_pix_gemm_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
-    "holo_pix_gemm_f32": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "holo_pix_gemm_f32": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "holo_conv_last_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "holo_conv_last_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "holo_conv_first_dgrad_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),

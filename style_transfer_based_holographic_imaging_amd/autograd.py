@@ -81,6 +81,22 @@ def _zero_bias(n, device):
     return z
 
 
+def _mosaic_per_row(b, h, w, c):
+    """images per mosaic row for the embedded gradients of a batch (0: separate blocks — a single image, or a mosaic past the
+    convolution kernels' 2^30 elements per image): the count whose tile-rounded area (32 x 16-pixel tiles) is smallest"""
+    if b <= 1:
+        return 0
+    best, best_area = 0, None
+    for gx in range(1, min(b, 8) + 1):
+        _, rows, width = ops.mosaic_shape(b, h, w, 2, True, gx)
+        if rows * width * c >= (1 << 30):
+            continue
+        area = -(-rows // 32) * 32 * (-(-width // 16) * 16)
+        if best_area is None or area < best_area:
+            best, best_area = gx, area
+    return best
+
+
 class ConvStep(torch.autograd.Function):
     """ReflectionPad2d(1) -> Conv2d(3x3) [-> ReLU] [-> MaxPool2d(2,2,ceil_mode=True)], NHWC fp32."""
 
@@ -103,13 +119,14 @@ class ConvStep(torch.autograd.Function):
         cout = w.shape[0]
         if y_act is None:
             y_act = x.new_empty((b, h, wd, cout))       # shape carrier only (neither ReLU nor pool reads it)
-        # the embedded gradient as ONE tall image (neighbours share their zero rows) while it stays under the convolution
-        # kernels' 2^30 elements per image: the data-gradient convolution then rounds the batch, not every image, up to whole tiles
-        # (32 x 32 maps in 32 x 16-pixel tiles: 54 tiles for 16 images instead of 96)
-        tall = b > 1 and ((b - 1) * (h + 2) + h + 4) * (wd + 4) * max(cin, cout) < (1 << 30)
+        # the embedded gradients of the batch as ONE image — a mosaic in which neighbours share their zero rows and columns — while
+        # it stays under the convolution kernels' 2^30 elements per image: the data-gradient convolution then rounds the batch, not
+        # every image, up to whole 32 x 16-pixel tiles (16 maps of 32 x 32: 96 tiles apart, 54 in one column, 45 as 3 rows of 7)
+        per_row = _mosaic_per_row(b, h, wd, max(cin, cout))
+        tall = per_row > 0
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         fused_bias = need_w and 1024 % cout == 0                    # the bias gradient summed by the mask / pad pass itself
-        dap = ops.relu_pool_bwd_pad(dy.contiguous(), y_act, y_pool, ctx.relu, 2, tall=tall, with_bias=fused_bias)
+        dap = ops.relu_pool_bwd_pad(dy.contiguous(), y_act, y_pool, ctx.relu, 2, tall=tall, with_bias=fused_bias, per_row=max(per_row, 1))
         dx = dw = db = None                                         # dap: (B, h+4, w+4, Cout) | (1, B(h+2)+2, w+4, Cout)
         if fused_bias:
             dap, db = dap
@@ -117,9 +134,9 @@ class ConvStep(torch.autograd.Function):
             if cin % 64 != 0:
                 raise NotImplementedError(f"data gradient of a {cin} -> {cout} convolution: the forward kernels need Cout % 64 == 0")
             dxp = _conv_fwd(dap, w, _zero_bias(cin, x.device), False, transposed=True)    # same shape as dap, Cin channels
-            dx = ops.fold_reflect(dxp, h, wd, 2, batch=b if tall else 0)
+            dx = ops.fold_reflect(dxp, h, wd, 2, batch=b if tall else 0, per_row=max(per_row, 1))
         if need_w:
-            dw = ops.pix_gemm(dap, 2, x, 9).view(cout, cin, 3, 3)
+            dw = ops.pix_gemm(dap, 2, x, 9, per_row=max(per_row, 1)).view(cout, cin, 3, 3)
             if db is None:
                 db = ops.channel_sum(dap)
         return dx, dw, db, None, None

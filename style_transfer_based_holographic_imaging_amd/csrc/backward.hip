@@ -55,30 +55,33 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict
 //   g = pool ? (y_act[y,x] is the FIRST maximum of its 2x2 window in scan order ? dy[y/2, x/2] : 0) : dy[y, x]
 //   out = relu ? (y_act > 0 ? g : 0) : g                      (torch: max_pool2d_backward routes to the stored argmax, the first
 //                                                              strict maximum; threshold_backward masks with the output > 0)
-// pitch = rows from one image's block to the next: h + 2*border (separate blocks), or less — down to h + border — for the TALL
+// MOSAIC.  pitch = rows from one image's block to the next: h + 2*border (separate blocks), or less — down to h + border — for the TALL
 // layout, where consecutive images share their zero rows (image n's lower border rows are image n + 1's upper ones): the whole batch
 // is then ONE image of (B - 1) * pitch + h + 2*border rows for the convolution that follows, which no longer rounds every image up
-// to whole tiles separately.
+// to whole tiles separately.  gx > 1 puts gx images side by side as well, cpitch = w + border columns apart (shared zero columns):
+// image n sits at (n / gx, n % gx), cells past the batch stay zero; the 16-pixel tile columns then round the mosaic's width.
 __global__ __launch_bounds__(256) void relu_pool_bwd_pad_kernel(const float* __restrict__ dy, const float* __restrict__ y_act,
                                                                 const float* __restrict__ y_pool, float* __restrict__ out, int batch,
-                                                                int h, int w, int c4, int relu, int border, int pitch, long total,
-                                                                double* __restrict__ bias_part) {
+                                                                int h, int w, int c4, int relu, int border, int pitch, int gx,
+                                                                int cpitch, int wp, long total, double* __restrict__ bias_part) {
     // grid-stride over the float4 elements; the stride is a multiple of c4 (c4 divides 256), so a thread stays on one channel quad
     // and can keep that quad's running sum (the bias gradient = sum of the masked gradient over pixels) in float64
     __shared__ double red[256][4];
     double bsum[4] = {0, 0, 0, 0};
-    const int wp = w + 2 * border;
+    const int img_rows = (batch + gx - 1) / gx;         // rows of images in the mosaic (gx side by side; gx = 1: a column of images)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int cq = (int)(i % c4);                   // = threadIdx.x % c4 on every trip when c4 divides 256 (the bias sums rely on it)
         long r = i / c4;
-        const int xp = (int)(r % wp);
+        const int xp = (int)(r % wp);                   // wp = pixel columns of the whole output
         r /= wp;                                        // row of the whole output
-        long n = r / pitch;
-        if (n > batch - 1) n = batch - 1;
-        const int yp = (int)(r - n * pitch);
-        const int y = yp - border, x = xp - border;
+        int nr = (int)(r / pitch);
+        if (nr > img_rows - 1) nr = img_rows - 1;
+        int nc = xp / cpitch;
+        if (nc > gx - 1) nc = gx - 1;
+        const long n = (long)nr * gx + nc;
+        const int y = (int)(r - (long)nr * pitch) - border, x = xp - nc * cpitch - border;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < h && x >= 0 && x < w) {
+        if (n < batch && y >= 0 && y < h && x >= 0 && x < w) {
             const float4* ya = reinterpret_cast<const float4*>(y_act) + n * h * (long)w * c4;
             const float4 a = relu || y_pool ? ya[((long)y * w + x) * c4 + cq] : g;
             if (y_pool) {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void relu_pool_bwd_pad_kernel(const float* __r
 
 // ---- adjoint of ReflectionPad2d(1): fold the pad ring of dXp (padded coordinates -1 .. h at index + border) onto the interior ----
 __global__ __launch_bounds__(256) void fold_reflect_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int h, int w, int c4,
-                                                           int border, int pitch, long total) {
+                                                           int border, int pitch, int gx, int cpitch, int wp, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int cq = (int)(i % c4);
@@ -137,8 +140,7 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel(const float* __restri
     r /= w;
     const int y = (int)(r % h);
     const long n = r / h;
-    const int wp = w + 2 * border;
-    const float4* src = reinterpret_cast<const float4*>(dxp) + n * pitch * (long)wp * c4;
+    const float4* src = reinterpret_cast<const float4*>(dxp) + ((n / gx) * pitch * (long)wp + (n % gx) * cpitch) * c4;   // wp: the buffer's columns
     // padded rows that reflect onto row y: y itself, -1 if y == 1, h if y == h - 2
     int ys[3], xs[3], ny = 0, nx = 0;
     ys[ny++] = y;
@@ -236,7 +238,7 @@ struct PixFrag {
 template <int TAPS, int NT>
 __global__ __launch_bounds__(256, 2) void pix_gemm_kernel(const float* __restrict__ p, int pb, const float* __restrict__ q,
                                                           float* __restrict__ part, int batch, int h, int w, int mc, int nc,
-                                                          int rows_per_wave, int ppitch) {
+                                                          int rows_per_wave, int ppitch, int gx, int cpitch, int pwidth) {
     constexpr int NB = TAPS * NT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hs = lane >> 5;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void pix_gemm_kernel(const float* __restric
     for (int t = 0; t < NB; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    const int hp = ppitch, wp = w + 2 * pb;          // image n's block of P starts at row n * ppitch
+    const int hp = ppitch, wp = pwidth;              // image n's block of P: row (n / gx) * ppitch, column (n % gx) * cpitch of a buffer pwidth wide
     const int xsteps = (w + 1) >> 1;
     const int steps = row1 > row0 ? (int)(row1 - row0) * xsteps : 0;
     if (steps > 0) {
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void pix_gemm_kernel(const float* __restric
             const int xx = cx + hs;
             const bool ok = xx < w && idx < steps;
             const int xc = xx < w ? xx : w - 1;
-            const float av = p[(((long)cn * hp + cy + pb) * wp + pb + xc) * mc + m0 + r];
+            const float av = p[(((long)(cn / gx) * hp + cy + pb) * wp + (cn % gx) * cpitch + pb + xc) * mc + m0 + r];
             f.a = av;
             f.ok = ok;
             if constexpr (TAPS == 9) {
@@ -342,7 +344,7 @@ constexpr int kPgLdsBytes = 2 * kPgPBytes + 4 * kPgQBytes;
 
 __global__ __launch_bounds__(256, 2) void pix_gemm9_lds_kernel(const float* __restrict__ p, int pb, const float* __restrict__ q,
                                                                float* __restrict__ part, int h, int w, int mc, int nc,
-                                                               int rows_per_unit, int groups, int ppitch) {
+                                                               int rows_per_unit, int groups, int ppitch, int gx, int cpitch, int pwidth) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kPgLdsBytes];
     const float* sf = reinterpret_cast<const float*>(smem);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void pix_gemm9_lds_kernel(const float* __re
     int y1 = y0 + rows_per_unit;
     if (y1 > h) y1 = h;
     const int cx0 = c * kPgChunk;
-    const int hp = ppitch, wp = w + 2 * pb;          // image n's block of P starts at row n * ppitch
+    const int hp = ppitch, wp = pwidth;              // image n's block of P: row (n / gx) * ppitch, column (n % gx) * cpitch of a buffer pwidth wide
     const unsigned lds_base = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem;
 
 #define PG_GLDS(sbase_, voff_, ldst_)                                                                      \
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void pix_gemm9_lds_kernel(const float* __re
     // a DMA piece = 4 pixels x 64 channels (1 KiB): lane -> pixel lane >> 4 of the piece, 4 channels from (lane & 15) * 4
     const int lpx = lane >> 4, lch = (lane & 15) * 4;
     auto fill_p = [&](int y, int buf) {               // 8 pieces, two per wave
-        const float* rowp = p + (((long)n * hp + y + pb) * wp + pb + cx0) * mc + m0;
+        const float* rowp = p + (((long)(n / gx) * hp + y + pb) * wp + (n % gx) * cpitch + pb + cx0) * mc + m0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int j = wave + 4 * k;
@@ -799,6 +801,21 @@ __global__ __launch_bounds__(256) void mask_scale_kernel(const float* __restrict
 
 static inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
+// the mosaic of embedded images (relu_pool_bwd_pad_kernel): rows between image blocks, images per mosaic row, columns between
+// them, and the buffer's size in pixels
+struct Mosaic {
+    int pitch, gx, cpitch, width;
+    long rows;
+};
+static inline bool mosaic_of(int batch, int h, int w, int border, int pitch_rows, int per_row, Mosaic& m) {
+    m.pitch = pitch_rows > 0 ? pitch_rows : h + 2 * border;
+    m.gx = per_row > 1 ? per_row : 1;
+    m.cpitch = m.gx > 1 ? w + border : w + 2 * border;
+    m.width = (m.gx - 1) * m.cpitch + w + 2 * border;
+    m.rows = (long)((batch + m.gx - 1) / m.gx - 1) * m.pitch + h + 2 * border;
+    return m.pitch >= h + border && m.pitch <= h + 2 * border && (m.gx == 1 || border >= 1);
+}
+
 constexpr int kFoldKeep = 64, kFoldBy = 32;
 constexpr int kPadBlocks = 2048;     // blocks of the mask / pad kernel when it also sums the bias gradient
 // rows of scratch behind `rows` partial rows that fold_rows() may use
@@ -890,22 +907,22 @@ size_t holo_relu_pool_bwd_pad_workspace_bytes(int c) {
     return c > 0 ? (size_t)(holo::kPadBlocks + holo::fold_scratch_rows(holo::kPadBlocks)) * c * sizeof(double) : 0;
 }
 int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float* y_pool, float* out_padded, int batch, int h, int w,
-                               int c, int relu, int border, int pitch_rows, float* dbias, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+                               int c, int relu, int border, int pitch_rows, int per_row, float* dbias, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     HOLO_REQUIRE(dy && out_padded && (y_act || (!relu && !y_pool)), HOLO_ERR_ARG, "holo_relu_pool_bwd_pad_f32: null pointer");
     HOLO_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && border >= 0 && border <= 2, HOLO_ERR_ARG,
                  "holo_relu_pool_bwd_pad_f32: batch=%d h=%d w=%d c=%d border=%d", batch, h, w, c, border);
-    const int pitch = pitch_rows > 0 ? pitch_rows : h + 2 * border;
-    HOLO_REQUIRE(pitch >= h + border && pitch <= h + 2 * border, HOLO_ERR_ARG,
-                 "holo_relu_pool_bwd_pad_f32: pitch_rows=%d outside [h + border, h + 2*border] = [%d, %d]", pitch_rows, h + border, h + 2 * border);
+    Mosaic mo;
+    HOLO_REQUIRE(mosaic_of(batch, h, w, border, pitch_rows, per_row, mo), HOLO_ERR_ARG,
+                 "holo_relu_pool_bwd_pad_f32: pitch_rows=%d outside [h + border, h + 2*border] = [%d, %d] (per_row=%d needs border >= 1)", pitch_rows,
+                 h + border, h + 2 * border, per_row);
     HOLO_REQUIRE(256 % (c / 4) == 0 || !dbias, HOLO_ERR_ARG, "holo_relu_pool_bwd_pad_f32: the bias gradient needs c in {4,...,1024} with 1024 %% c == 0 (c=%d)", c);
     HOLO_REQUIRE(!dbias || (workspace && workspace_bytes >= holo_relu_pool_bwd_pad_workspace_bytes(c)), HOLO_ERR_WORKSPACE,
                  "holo_relu_pool_bwd_pad_f32: the bias gradient needs a workspace of %zu bytes", holo_relu_pool_bwd_pad_workspace_bytes(c));
-    const long rows = (long)(batch - 1) * pitch + h + 2 * border;
-    const long total = rows * (w + 2 * border) * (c / 4);
+    const long total = mo.rows * mo.width * (c / 4);
     const unsigned blocks = blocks_for(total) < (unsigned)kPadBlocks || !dbias ? blocks_for(total) : (unsigned)kPadBlocks;
     hipLaunchKernelGGL(relu_pool_bwd_pad_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, y_act, y_pool, out_padded, batch,
-                       h, w, c / 4, relu, border, pitch, total, dbias ? static_cast<double*>(workspace) : nullptr);
+                       h, w, c / 4, relu, border, mo.pitch, mo.gx, mo.cpitch, mo.width, total, dbias ? static_cast<double*>(workspace) : nullptr);
     if (dbias) {
         int left = (int)blocks;
         const double* folded = fold_rows(static_cast<double*>(workspace), c, left, as_stream(stream));
@@ -914,15 +931,16 @@ int holo_relu_pool_bwd_pad_f32(const float* dy, const float* y_act, const float*
     return check_launch("holo_relu_pool_bwd_pad_f32");
 }
 
-int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, int pitch_rows, void* stream) {
+int holo_fold_reflect_f32(const float* dxp, float* dx, int batch, int h, int w, int c, int border, int pitch_rows, int per_row,
+                          void* stream) {
     HOLO_REQUIRE(dxp && dx, HOLO_ERR_ARG, "holo_fold_reflect_f32: null pointer");
     HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && c > 0 && c % 4 == 0 && border >= 1 && border <= 2, HOLO_ERR_ARG,
                  "holo_fold_reflect_f32: batch=%d h=%d w=%d c=%d border=%d (reflection padding needs h,w >= 2)", batch, h, w, c, border);
-    const int pitch = pitch_rows > 0 ? pitch_rows : h + 2 * border;
-    HOLO_REQUIRE(pitch >= h + border && pitch <= h + 2 * border, HOLO_ERR_ARG,
+    Mosaic mo;
+    HOLO_REQUIRE(mosaic_of(batch, h, w, border, pitch_rows, per_row, mo), HOLO_ERR_ARG,
                  "holo_fold_reflect_f32: pitch_rows=%d outside [h + border, h + 2*border] = [%d, %d]", pitch_rows, h + border, h + 2 * border);
     const long total = (long)batch * h * w * (c / 4);
-    hipLaunchKernelGGL(fold_reflect_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dxp, dx, h, w, c / 4, border, pitch, total);
+    hipLaunchKernelGGL(fold_reflect_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), dxp, dx, h, w, c / 4, border, mo.pitch, mo.gx, mo.cpitch, mo.width, total);
     return check_launch("holo_fold_reflect_f32");
 }
 
@@ -960,14 +978,14 @@ size_t holo_pix_gemm_workspace_bytes(int batch, int h, int w, int mc, int nc, in
 }
 /* out[m][n][tap] = sum over the B*h*w pixels of P[pixel][m] * Q[reflect(pixel + tap)][n]; taps = 9 (3x3, tap = ky*3+kx, reflected
  * neighbour) or 1 (the pixel itself).  P: (B, h + 2*p_border, w + 2*p_border, mc) NHWC read at its interior, Q: (B, h, w, nc). */
-int holo_pix_gemm_f32(const float* p, int p_border, int p_pitch_rows, const float* q, float* out, int batch, int h, int w, int mc, int nc,
-                      int taps, void* workspace, size_t workspace_bytes, void* stream) {
+int holo_pix_gemm_f32(const float* p, int p_border, int p_pitch_rows, int p_per_row, const float* q, float* out, int batch, int h, int w,
+                      int mc, int nc, int taps, void* workspace, size_t workspace_bytes, void* stream) {
     HOLO_REQUIRE(p && q && out && workspace, HOLO_ERR_ARG, "holo_pix_gemm_f32: null pointer");
     HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2 && mc > 0 && nc > 0 && mc % 32 == 0 && nc % 32 == 0 && (taps == 1 || taps == 9) && p_border >= 0,
                  HOLO_ERR_ARG, "holo_pix_gemm_f32: batch=%d h=%d w=%d mc=%d nc=%d taps=%d (channels %% 32, taps 1 | 9)", batch, h, w, mc, nc, taps);
     HOLO_REQUIRE(workspace_bytes >= holo_pix_gemm_workspace_bytes(batch, h, w, mc, nc, taps), HOLO_ERR_WORKSPACE, "holo_pix_gemm_f32: workspace too small");
-    const int ppitch = p_pitch_rows > 0 ? p_pitch_rows : h + 2 * p_border;
-    HOLO_REQUIRE(ppitch >= h + p_border && ppitch <= h + 2 * p_border, HOLO_ERR_ARG,
+    Mosaic mo;
+    HOLO_REQUIRE(mosaic_of(batch, h, w, p_border, p_pitch_rows, p_per_row, mo), HOLO_ERR_ARG,
                  "holo_pix_gemm_f32: p_pitch_rows=%d outside [h + border, h + 2*border] = [%d, %d]", p_pitch_rows, h + p_border, h + 2 * p_border);
     float* part = static_cast<float*>(workspace);
     const long elems = (long)mc * nc * taps;
@@ -975,7 +993,7 @@ int holo_pix_gemm_f32(const float* p, int p_border, int p_pitch_rows, const floa
         const PixGemmLdsPlan lp = pix_gemm_lds_plan(batch, h, w, mc, nc);
         HOLO_REQUIRE(lp.units <= 65535, HOLO_ERR_ARG, "holo_pix_gemm_f32: %ld work units (grid limit 65535)", lp.units);
         hipLaunchKernelGGL(pix_gemm9_lds_kernel, dim3(mc / 64, nc / 64, (unsigned)lp.units), dim3(256), 0, as_stream(stream), p, p_border, q, part,
-                           h, w, mc, nc, lp.rows_per_unit, lp.groups, ppitch);
+                           h, w, mc, nc, lp.rows_per_unit, lp.groups, mo.pitch, mo.gx, mo.cpitch, mo.width);
         int left = (int)lp.units;
         const float* folded = fold_rows(part, elems, left, as_stream(stream));
         hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), folded, out, elems, left, taps, 1);
@@ -985,11 +1003,11 @@ int holo_pix_gemm_f32(const float* p, int p_border, int p_pitch_rows, const floa
     const PixGemmPlan pl = pix_gemm_plan(batch, h, mc, nc, nt);
     const dim3 grid(mc / 32, nc / (32 * nt), pl.splits);
     if (taps == 9)
-        hipLaunchKernelGGL((pix_gemm_kernel<9, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, ppitch);
+        hipLaunchKernelGGL((pix_gemm_kernel<9, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, mo.pitch, mo.gx, mo.cpitch, mo.width);
     else if (nt == 4)
-        hipLaunchKernelGGL((pix_gemm_kernel<1, 4>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, ppitch);
+        hipLaunchKernelGGL((pix_gemm_kernel<1, 4>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, mo.pitch, mo.gx, mo.cpitch, mo.width);
     else
-        hipLaunchKernelGGL((pix_gemm_kernel<1, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, ppitch);
+        hipLaunchKernelGGL((pix_gemm_kernel<1, 1>), grid, dim3(256), 0, as_stream(stream), p, p_border, q, part, batch, h, w, mc, nc, pl.rows_per_wave, mo.pitch, mo.gx, mo.cpitch, mo.width);
     int left = (int)pl.slots;
     const float* folded = fold_rows(part, elems, left, as_stream(stream));
     hipLaunchKernelGGL(pix_gemm_reduce_kernel, dim3(blocks_for(elems)), dim3(256), 0, as_stream(stream), folded, out, elems, left, taps, 0);

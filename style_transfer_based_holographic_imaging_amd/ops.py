@@ -598,45 +598,53 @@ def maxpool2x2(x_nhwc: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def relu_pool_bwd_pad(dy, y_act, y_pool, relu: bool, border: int, tall: bool = False, with_bias: bool = False):
+def mosaic_shape(b: int, h: int, w: int, border: int, tall: bool, per_row: int = 1):
+    """(pitch_rows, rows, width) of the buffer holo_relu_pool_bwd_pad_f32 writes: separate blocks (tall False), one tall image
+    (neighbours share their zero rows), or a mosaic with ``per_row`` images side by side (sharing zero columns too)."""
+    gx = per_row if per_row and per_row > 1 else 1
+    assert gx == 1 or tall, "images side by side come with the shared-row layout"
+    pitch = h + border if tall else h + 2 * border
+    rows = ((b + gx - 1) // gx - 1) * pitch + h + 2 * border if tall else h + 2 * border
+    width = (gx - 1) * (w + border) + w + 2 * border
+    return pitch, rows, width
+
+
+def relu_pool_bwd_pad(dy, y_act, y_pool, relu: bool, border: int, tall: bool = False, with_bias: bool = False, per_row: int = 1):
     """Gradient of a conv step's pre-activation embedded in a zero border: dy routed through the (optional) max-pool and masked
     by the (optional) ReLU.  y_act: (B,h,w,c) post-ReLU pre-pool output; dy, y_pool: pooled shape when y_pool is given.
-    tall: ONE image (1, (B-1)*(h+border) + h + 2*border, w + 2*border, c) in which neighbouring images share their zero rows
-    (image n's block starts at row n*(h+border)) instead of (B, h+2*border, w+2*border, c).
+    tall: ONE image (1, rows, width, c) in which neighbouring images share their zero rows (and, with per_row > 1 images side by
+    side, their zero columns: mosaic_shape) instead of (B, h+2*border, w+2*border, c).
     with_bias: also returns the bias gradient (c), summed in the same pass."""
     _req(dy, y_act)
     dy, y_act = _f32c(dy), _f32c(y_act)
     b, h, w, c = y_act.shape
     yp = _f32c(y_pool) if y_pool is not None else None
-    pitch = h + border if tall else h + 2 * border
-    shape = (1, (b - 1) * pitch + h + 2 * border, w + 2 * border, c) if tall else (b, h + 2 * border, w + 2 * border, c)
+    pitch, rows, width = mosaic_shape(b, h, w, border, tall, per_row)
+    shape = (1, rows, width, c) if tall else (b, rows, width, c)
     out = torch.empty(shape, dtype=torch.float32, device=dy.device)
     dbias = torch.empty((c,), dtype=torch.float32, device=dy.device) if with_bias else None
     n = lib.holo_relu_pool_bwd_pad_workspace_bytes(c) if with_bias else 0
     ws = _ws(n, dy.device) if with_bias else None
     _launch("holo_relu_pool_bwd_pad_f32",
             lambda: lib.holo_relu_pool_bwd_pad_f32(dy.data_ptr(), y_act.data_ptr(), yp.data_ptr() if yp is not None else 0, out.data_ptr(),
-                                                   b, h, w, c, int(bool(relu)), int(border), int(pitch),
+                                                   b, h, w, c, int(bool(relu)), int(border), int(pitch), int(per_row),
                                                    dbias.data_ptr() if with_bias else 0, ws.data_ptr() if with_bias else 0, n, _stream()),
             nbytes=12.0 * b * h * w * c)
     return (out, dbias) if with_bias else out
 
 
-def fold_reflect(dxp, h: int, w: int, border: int, batch: int = 0) -> torch.Tensor:
-    """Adjoint of ReflectionPad2d(1): (B,h+2*border,w+2*border,c) -> (B,h,w,c); with ``batch`` the input is the tall layout of
-    relu_pool_bwd_pad (one image, blocks h+border rows apart)."""
+def fold_reflect(dxp, h: int, w: int, border: int, batch: int = 0, per_row: int = 1) -> torch.Tensor:
+    """Adjoint of ReflectionPad2d(1): (B,h+2*border,w+2*border,c) -> (B,h,w,c); with ``batch`` the input is the tall / mosaic
+    layout of relu_pool_bwd_pad (one image holding the whole batch)."""
     _req(dxp)
     dxp = _f32c(dxp)
     b, hp, wp, c = dxp.shape
-    if batch:
-        pitch = h + border
-        assert b == 1 and hp == (batch - 1) * pitch + h + 2 * border and wp == w + 2 * border
-        b = batch
-    else:
-        pitch = h + 2 * border
-        assert hp == pitch and wp == w + 2 * border
+    pitch, rows, width = mosaic_shape(batch or b, h, w, border, bool(batch), per_row)
+    assert (b == 1 if batch else True) and hp == rows and wp == width, (dxp.shape, rows, width)
+    b = batch or b
     dx = torch.empty((b, h, w, c), dtype=torch.float32, device=dxp.device)
-    _launch("holo_fold_reflect_f32", lambda: lib.holo_fold_reflect_f32(dxp.data_ptr(), dx.data_ptr(), b, h, w, c, int(border), int(pitch), _stream()),
+    _launch("holo_fold_reflect_f32", lambda: lib.holo_fold_reflect_f32(dxp.data_ptr(), dx.data_ptr(), b, h, w, c, int(border), int(pitch), int(per_row),
+                                                                       _stream()),
             nbytes=8.0 * b * h * w * c)
     return dx
 
@@ -686,24 +694,22 @@ def channel_sum(x_rows_c: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pix_gemm(p_padded, p_border: int, q, taps: int) -> torch.Tensor:
+def pix_gemm(p_padded, p_border: int, q, taps: int, per_row: int = 1) -> torch.Tensor:
     """out[m][n][tap] = sum over pixels P[pixel][m] * Q[reflect(pixel + tap)][n] (weight gradients; fp32 MFMA, deterministic).
-    P: (B, h+2*border, w+2*border, mc), or the tall layout of relu_pool_bwd_pad (one image, blocks h+border rows apart)."""
+    P: (B, h+2*border, w+2*border, mc), or the tall / mosaic layout of relu_pool_bwd_pad (one image holding the whole batch,
+    ``per_row`` images side by side)."""
     _req(p_padded, q)
     p_padded, q = _f32c(p_padded), _f32c(q)
     b, h, w, nc = q.shape
     mc = p_padded.shape[-1]
-    assert p_padded.shape[2] == w + 2 * p_border
-    if p_padded.shape[0] == b and p_padded.shape[1] == h + 2 * p_border:
-        pitch = h + 2 * p_border
-    else:
-        pitch = h + p_border
-        assert p_padded.shape[0] == 1 and p_padded.shape[1] == (b - 1) * pitch + h + 2 * p_border
+    tall = not (p_padded.shape[0] == b and p_padded.shape[1] == h + 2 * p_border and per_row <= 1)
+    pitch, rows, width = mosaic_shape(b, h, w, p_border, tall, per_row)
+    assert p_padded.shape[0] == (1 if tall else b) and p_padded.shape[1] == rows and p_padded.shape[2] == width, (p_padded.shape, rows, width)
     out = torch.empty((mc, nc, taps), dtype=torch.float32, device=q.device)
     n = lib.holo_pix_gemm_workspace_bytes(b, h, w, mc, nc, taps)
     ws = _ws(n, q.device)
-    _launch("holo_pix_gemm_f32", lambda: lib.holo_pix_gemm_f32(p_padded.data_ptr(), int(p_border), int(pitch), q.data_ptr(), out.data_ptr(), b, h, w,
-                                                               mc, nc, int(taps), ws.data_ptr(), n, _stream()),
+    _launch("holo_pix_gemm_f32", lambda: lib.holo_pix_gemm_f32(p_padded.data_ptr(), int(p_border), int(pitch), int(per_row), q.data_ptr(), out.data_ptr(),
+                                                               b, h, w, mc, nc, int(taps), ws.data_ptr(), n, _stream()),
             flops=2.0 * taps * mc * nc * b * h * w, nbytes=4.0 * (p_padded.numel() + q.numel()))
     return out
 

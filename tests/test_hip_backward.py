@@ -56,6 +56,30 @@ def test_conv_step(ag, dev, b, h, w, cin, cout, relu, pool):
     assert rel_err(bd.grad.cpu(), br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("gx,b,h,w,cin,cout,pool", [(2, 4, 6, 32, 64, 64, False), (3, 5, 9, 10, 64, 128, True), (4, 4, 8, 32, 128, 64, False),
+                                                    (2, 3, 33, 64, 64, 64, True)])
+def test_conv_step_in_a_mosaic(ag, dev, monkeypatch, gx, b, h, w, cin, cout, pool):
+    """the embedded gradients laid out gx images per mosaic row (shared zero rows AND columns; the last row ragged where gx does
+    not divide the batch): same gradients as torch, through both weight-gradient kernels"""
+    monkeypatch.setattr(ag, "_mosaic_per_row", lambda *a: gx)
+    g = torch.Generator().manual_seed(gx * 100 + b)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), bias.clone().requires_grad_()
+    y = F.relu(F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr, br))
+    if pool:
+        y = F.max_pool2d(y, 2, 2, 0, ceil_mode=True)
+    up = torch.randn(y.shape, generator=g)
+    (y * up).sum().backward()
+    xd, wd, bd = _nhwc(x, dev).requires_grad_(), wt.to(dev).requires_grad_(), bias.to(dev).requires_grad_()
+    yd = ag.ConvStep.apply(xd, wd, bd, True, pool)
+    (yd * _nhwc(up, dev)).sum().backward()
+    assert rel_err(xd.grad.permute(0, 3, 1, 2).cpu(), xr.grad) < 2e-5
+    assert rel_err(wd.grad.cpu(), wr.grad) < 2e-5
+    assert rel_err(bd.grad.cpu(), br.grad) < 2e-5
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout,relu", [(2, 5, 7, 64, 64, False), (1, 9, 20, 256, 128, True), (1, 3, 3, 1024, 256, False),
                                                  (3, 17, 16, 512, 192, True)])
 def test_conv1x1(dev, b, h, w, cin, cout, relu):

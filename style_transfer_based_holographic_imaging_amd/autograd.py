@@ -121,7 +121,7 @@ class ConvStep(torch.autograd.Function):
             y_act = x.new_empty((b, h, wd, cout))       # shape carrier only (neither ReLU nor pool reads it)
         # the embedded gradients of the batch as ONE image — a mosaic in which neighbours share their zero rows and columns — while
         # it stays under the convolution kernels' 2^30 elements per image: the data-gradient convolution then rounds the batch, not
-        # every image, up to whole 32 x 16-pixel tiles (16 maps of 32 x 32: 96 tiles apart, 54 in one column, 45 as 3 rows of 7)
+        # every image, up to whole 32 x 16-pixel tiles (16 maps of 32 x 32: 96 tiles apart, 54 in one column, 45 as 8 rows of 2)
         per_row = _mosaic_per_row(b, h, wd, max(cin, cout))
         tall = per_row > 0
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]

@@ -7,14 +7,18 @@
 //     PADDED domain, then the adjoint of the reflection folds the pad ring back (row -1 onto row 1, row H onto row H-2).  The
 //     correlation is the FORWARD convolution kernel (Winograd / implicit GEMM, conv_winograd.hip / conv_mfma.hip) run on dA embedded
 //     in a zero border of TWO pixels: the forward kernel's own reflection then only ever mirrors zeros.  relu_pool_bwd_pad_kernel
-//     builds that embedded tensor (ReLU mask and max-pool routing applied on the way), fold_reflect_kernel does the fold.
-//   * weight gradient: dW[m][n][tap] = sum over pixels of P[pixel][m] * Q[pixel + tap][n] — a GEMM whose K runs over PIXELS
-//     (pix_gemm_kernel, v_mfma_f32_32x32x2_f32, operands straight from global memory: a pixel's channels are contiguous, so a
-//     lane group's 32 channels of one pixel are one 128-byte segment).  Partial sums per (pixel range, wave) go to a workspace
-//     and are added in a fixed order (deterministic, like the split-K forward).
-//   * ConvTranspose2d(k2,s2): its data gradient is a 1x1 convolution of the space-to-depth gradient (B,H,W,4*Cout) — run as a
-//     3x3 forward convolution with a centre-only kernel; its weight gradient is pix_gemm with one tap.
-//   * the skinny layers (3 -> 64 first, 64 -> 2 last), statistics and the distance head: small VALU kernels.
+//     builds that embedded tensor (ReLU mask and max-pool routing applied on the way, the bias gradient summed in the same pass) —
+//     for a batch as ONE mosaic image whose neighbours share their zero rows and columns, so that the convolution rounds the
+//     batch, not every image, up to whole tiles; fold_reflect_kernel does the fold.
+//   * weight gradient: dW[m][n][tap] = sum over pixels of P[pixel][m] * Q[pixel + tap][n] — a GEMM whose K runs over PIXELS on
+//     v_mfma_f32_32x32x2_f32.  pix_gemm9_lds_kernel (whole 32-pixel strips, channels % 64): both operands staged through LDS by
+//     LDS-DMA, a ring of four Q rows serving the three vertical taps; pix_gemm_kernel (other widths, the one-tap case): operands
+//     straight from global memory.  Partial tiles go to a workspace and are folded 32 to 1 in a fixed order (deterministic).
+//   * ConvTranspose2d(k2,s2): its data gradient is a 1x1 convolution of the space-to-depth gradient (B,H,W,4*Cout) — the transposed
+//     convolution's own one-tap GEMM with a plain store (holo_conv1x1_f32, conv_mfma.hip); its weight gradient is pix_gemm with
+//     one tap.
+//   * the skinny layers (3 -> 64 first, 64 -> 2 last), statistics (pixel-split for large maps), the distance head and its
+//     training-mode Dropout: small VALU kernels.
 //
 // Everything is exact fp32 arithmetic; results differ from torch.autograd by summation order only (tests/test_hip_backward.py).
 #include <algorithm>

@@ -187,7 +187,7 @@ def main():
         for c0 in range(0, hi - lo, 64):        # forward propagation in pieces of 64 (the generator's own chunking is index-based)
             ph_c, d_c = ph_j[c0:c0 + 64].to(dev), d_j[c0:c0 + 64].to(dev)
             with torch.no_grad():
-                chunks.append(torch.sqrt(model_forward(torch.full_like(ph_c, 0.6), ph_c, d_c)))
+                chunks.append(model_forward(torch.full_like(ph_c, 0.6), ph_c, d_c))   # hologram INTENSITY: the step takes the sqrt (below)
         content = torch.cat(chunks, 0).contiguous() if chunks else torch.empty((0, 1, s, s), device=dev)
         del chunks, ph_j, d_j
         n_local = hi - lo
@@ -203,13 +203,15 @@ def main():
         d_content = synth.synthetic_distances(b, seed=seed).to(dev)
         d_style = torch.full((b, 1, 1, 1), -0.2, device=dev)             # back-propagation: -distance_style (test_field_retrieval_mnist.py:126)
         with torch.no_grad():
-            content = torch.sqrt(model_forward(torch.full_like(ph, 0.6), ph, d_content)).contiguous()
+            content = model_forward(torch.full_like(ph, 0.6), ph, d_content).contiguous()   # hologram INTENSITY, as the entry loop loads it
         del ph
 
     sweep_d = torch.linspace(-0.1, -0.8, max(args.distances, 2), device=dev)[:args.distances]
 
     def one_batch(x, d_st):
-        amp, p, d = field_retrieval(network, x, style, 1.0, True)
+        # test_field_retrieval_mnist.py:119 + 125: sqrt(content_holo) is part of the per-batch work; here the first layer's loader
+        # takes it (bit-identical to torch.sqrt first)
+        amp, p, d = field_retrieval(network, x, style, 1.0, True, intensity=True)
         if args.distances > 1:   # utils/Data_loader.py:59-62 idiom: one field, a list of distances
             a_f, p_f = model_forward.sweep(amp, p, sweep_d)           # (the entry loop's `ph_field * phase_normalize` is the kernel's phase_scale)
         else:

@@ -69,6 +69,14 @@ size_t holo_convt2x2_packed_elems(int cin, int cout);
  * w1: the 3x3 conv weight in its native (64,3,3,3) OIHW order; b1: 64;  y: NHWC (B,H,W,64). */
 int holo_conv_first_f32(const float* x, const float* w0, const float* b0, const float* w1,
                         const float* b1, float* y_nhwc, int batch, int h, int w, void* stream);
+/* the same layers fed with the hologram INTENSITY: the sqrt of the entry loop (test_field_retrieval_mnist.py:119) applied by the
+ * loader, correctly rounded; bit-identical to a correctly rounded sqrt followed by holo_conv_first_* */
+int holo_conv_first_sqrt_f32(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                             float* y_nhwc, int batch, int h, int w, void* stream);
+int holo_conv_first_sqrt_bf16(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                              uint16_t* y_nhwc, int batch, int h, int w, void* stream);
+int holo_conv_first_sqrt_f32s(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                              void* y_nhwc, int batch, int h, int w, void* stream);
 
 /* ReflectionPad2d(1) -> Conv2d(Cin,Cout,3x3) -> [ReLU] -> [MaxPool2d(2,2,ceil_mode=True)]
  * (every "c3" layer of net.py:33-107).  x: NHWC (B,H,W,Cin); w_packed from

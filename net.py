@@ -114,9 +114,10 @@ class Net(nn.Module):
             results.append(getattr(self, "enc_{:d}".format(i + 1))(results[-1]))
         return [self._public(r) for r in results[1:]]
 
-    def _encode(self, input):
+    def _encode(self, input, intensity=False):
         for i in range(self.n_layer):
-            input = getattr(self, "enc_{:d}".format(i + 1))(input)
+            stage = getattr(self, "enc_{:d}".format(i + 1))
+            input = stage(input, intensity=True) if (intensity and i == 0) else stage(input)
         return input
 
     def encode(self, input):
@@ -174,9 +175,11 @@ class Net(nn.Module):
             return loss_c, loss_s, g_t, g_t_phase, style_re
         return loss_c, loss_s
 
-    def field_retrieval(self, content, style_feats, alpha=1.0, unknown_distance=False):
+    def field_retrieval(self, content, style_feats, alpha=1.0, unknown_distance=False, intensity=False):
+        """net.py:228-260.  ``intensity`` (additive): ``content`` is the hologram intensity and the first layer's loader takes the
+        square root — the entry loop's ``torch.sqrt(content_holo)`` (test_field_retrieval_mnist.py:119) without its own pass."""
         assert 0 <= alpha <= 1
-        content_feat = self._encode(content)                     # logical NCHW, channels-last memory
+        content_feat = self._encode(content, intensity)          # logical NCHW, channels-last memory
         feat_nhwc = ops.to_nhwc(content_feat)                    # free view
         b = content.shape[0]
         style_feats = style_feats.to(device=content_feat.device, dtype=torch.float32)

@@ -35,6 +35,9 @@ SIGNATURES = {
     "holo_pack_convt2x2_weight_f32": (_i, [_p, _p, _i, _i, _p]),
     "holo_convt2x2_packed_elems": (_z, [_i, _i]),
     "holo_conv_first_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_conv_first_sqrt_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_conv_first_sqrt_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "holo_conv_first_sqrt_f32s": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "holo_conv3x3_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "holo_pack_conv3x3_wino_weight_f32": (_i, [_p, _p, _i, _i, _p]),
     "holo_conv3x3_wino_packed_elems": (_z, [_i, _i]),

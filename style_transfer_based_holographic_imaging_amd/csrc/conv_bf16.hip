@@ -754,7 +754,7 @@ int conv_last_b16_try(const void* x, const float* w, const float* bias, float* y
 __global__ __launch_bounds__(256, 3) void conv_first_b16_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                                 const float* __restrict__ b0, const float* __restrict__ w1,
                                                                 const float* __restrict__ b1, b16_t* __restrict__ y, int H, int W,
-                                                                int tiles_x, int tiles_y, int total_tiles) {
+                                                                int tiles_x, int tiles_y, int total_tiles, int sqrt_in) {
     constexpr int HW = 18;
     __shared__ float halo[HW * HW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -797,7 +797,8 @@ __global__ __launch_bounds__(256, 3) void conv_first_b16_kernel(const float* __r
         __syncthreads();      // the previous tile's halo is consumed
         for (int i = tid; i < HW * HW; i += 256) {
             const int hy = i / HW, hx = i % HW;
-            halo[i] = xi[reflect1(cur.y0 - 1 + hy, H) * W + reflect1(cur.x0 - 1 + hx, W)];
+            const float v = xi[reflect1(cur.y0 - 1 + hy, H) * W + reflect1(cur.x0 - 1 + hx, W)];
+            halo[i] = sqrt_in ? sqrtf(v) : v;     // intensity in (holo_conv_first_sqrt_*); sqrtf: correctly rounded
         }
         __syncthreads();
         f32x4 acc[4][4];
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(256, 3) void conv_first_b16_kernel(const float* __r
 }
 
 int conv_first_b16_try(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* y, int batch, int h,
-                       int w_px, hipStream_t stream) {
+                       int w_px, int sqrt_in, hipStream_t stream) {
     const int tiles_x = ceil_div(w_px, 16), tiles_y = ceil_div(h, 16);
     const long tiles = (long)batch * tiles_x * tiles_y;
     // per image, open batch bucket only (common.h kOpenBatchBucket): images of >= 64 tiles (128 x 128)
@@ -832,7 +833,7 @@ int conv_first_b16_try(const float* x, const float* w0, const float* b0, const f
     const long slots = (long)device_cus() * 3;
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
     hipLaunchKernelGGL(conv_first_b16_kernel, dim3(grid), dim3(256), 0, stream, x, w0, b0, w1, b1, static_cast<b16_t*>(y), h, w_px, tiles_x,
-                       tiles_y, (int)tiles);
+                       tiles_y, (int)tiles, sqrt_in);
     return check_launch("holo_conv_first_bf16");
 }
 

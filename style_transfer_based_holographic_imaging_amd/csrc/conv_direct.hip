@@ -31,7 +31,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                          const float* __restrict__ b0, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, T* __restrict__ y, int H, int W,
-                                                         int tiles_x, int tiles_y) {
+                                                         int tiles_x, int tiles_y, int sqrt_in) {
     __shared__ float halo[kFH * kFH];
     __shared__ float wl[64 * kFWS];
     __shared__ __attribute__((aligned(16))) T stage[4][32 * 64];   // per wave: one M tile as [pixel][co]
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
     const float* __restrict__ xi = x + (size_t)img * H * W;
     for (int i = tid; i < kFH * kFH; i += 256) {
         const int hy = i / kFH, hx = i % kFH;
-        halo[i] = xi[reflect1(y0 - 1 + hy, H) * W + reflect1(x0 - 1 + hx, W)];
+        const float v = xi[reflect1(y0 - 1 + hy, H) * W + reflect1(x0 - 1 + hx, W)];
+        halo[i] = sqrt_in ? sqrtf(v) : v;     // intensity in (sqrtf is correctly rounded here, __fsqrt_rn is not): torch.sqrt(content_holo) of the entry loop (test_field_retrieval_mnist.py:119) in the loader
     }
     for (int i = tid; i < 64 * kFK; i += 256) {
         const int co = i / kFK, k = i % kFK;
@@ -247,11 +248,11 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const T* __restrict__ x,
 
 // conv_bf16.hip: the first layer as one split-bf16 MFMA step for bf16 activations; -1 when it does not take the problem
 int conv_first_b16_try(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* y, int batch, int h,
-                       int w_px, hipStream_t stream);
+                       int w_px, int sqrt_in, hipStream_t stream);
 
 template <typename T>
 static int conv_first_entry(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, T* y_nhwc,
-                            int batch, int h, int w, void* stream) {
+                            int batch, int h, int w, void* stream, int sqrt_in = 0) {
     HOLO_REQUIRE(x && w0 && b0 && w1 && b1 && y_nhwc, HOLO_ERR_ARG, "holo_conv_first: null pointer");
     HOLO_REQUIRE(batch > 0 && h >= 2 && w >= 2, HOLO_ERR_ARG,
                  "holo_conv_first: batch=%d h=%d w=%d (reflection padding needs h,w >= 2)", batch, h, w);
@@ -260,12 +261,12 @@ static int conv_first_entry(const float* x, const float* w0, const float* b0, co
     HOLO_REQUIRE(blocks < 2147483647L, HOLO_ERR_UNSUPPORTED, "holo_conv_first: grid of %ld blocks", blocks);
     if constexpr (__is_same(T, bf16_t)) {
         if (conv_tile_override() != 1) {     // holo_debug_set_conv_tile(1) keeps the fp32-MFMA kernel (A/B, tests)
-            const int r = conv_first_b16_try(x, w0, b0, w1, b1, y_nhwc, batch, h, w, as_stream(stream));
+            const int r = conv_first_b16_try(x, w0, b0, w1, b1, y_nhwc, batch, h, w, sqrt_in, as_stream(stream));
             if (r >= 0) return r;
         }
     }
     hipLaunchKernelGGL((conv_first_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, w0, b0, w1, b1,
-                       y_nhwc, h, w, tiles_x, tiles_y);
+                       y_nhwc, h, w, tiles_x, tiles_y, sqrt_in);
     return check_launch("holo_conv_first");
 }
 
@@ -306,6 +307,20 @@ extern "C" {
 int holo_conv_first_f32(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
                         float* y_nhwc, int batch, int h, int w, void* stream) {
     return holo::conv_first_entry<float>(x, w0, b0, w1, b1, y_nhwc, batch, h, w, stream);
+}
+/* the same layers fed with the hologram INTENSITY: sqrt (correctly rounded, = torch.sqrt) applied by the loader
+ * (test_field_retrieval_mnist.py:119 folded into vgg[0:4]) */
+int holo_conv_first_sqrt_f32(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* y_nhwc, int batch,
+                             int h, int w, void* stream) {
+    return holo::conv_first_entry<float>(x, w0, b0, w1, b1, y_nhwc, batch, h, w, stream, 1);
+}
+int holo_conv_first_sqrt_bf16(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, uint16_t* y_nhwc,
+                              int batch, int h, int w, void* stream) {
+    return holo::conv_first_entry<holo::bf16_t>(x, w0, b0, w1, b1, reinterpret_cast<holo::bf16_t*>(y_nhwc), batch, h, w, stream, 1);
+}
+int holo_conv_first_sqrt_f32s(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, void* y_nhwc, int batch,
+                              int h, int w, void* stream) {
+    return holo::conv_first_entry<holo::split16>(x, w0, b0, w1, b1, static_cast<holo::split16*>(y_nhwc), batch, h, w, stream, 1);
 }
 int holo_conv_first_bf16(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
                          uint16_t* y_nhwc, int batch, int h, int w, void* stream) {

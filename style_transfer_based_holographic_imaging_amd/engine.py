@@ -193,7 +193,7 @@ class Plan:
     def ends_in_planes(self):
         return bool(self.steps) and self.steps[-1].kind == "last"
 
-    def run_step(self, idx, x):
+    def run_step(self, idx, x, intensity=False):
         st = self.steps[idx]
         if st.kind == "conv" and x.dtype == torch.float32:
             use_wino, ksplit = self._wino_choice(st, x)
@@ -204,7 +204,7 @@ class Plan:
         if st.kind == "first":
             if x.dim() != 4 or x.shape[1] != 1:
                 raise RuntimeError(f"the encoder expects a (B,1,H,W) hologram amplitude, got {tuple(x.shape)}")
-            return ops.conv_first(x, *wts, out_dtype=self.dtype)
+            return ops.conv_first(x, *wts, out_dtype=self.dtype, sqrt_input=intensity)
         if st.kind in ("conv", "convt") and x.dtype != self.dtype:
             x = ops.cast(x, self.dtype)
         if st.kind == "conv":
@@ -213,8 +213,9 @@ class Plan:
             return ops.convt2x2(x, wts[0], wts[1], st.conv.out_channels, st.relu)
         return ops.conv_last(x, wts[0], wts[1])
 
-    def run(self, x):
+    def run(self, x, intensity=False):
         """x: logical (B,C,H,W) for a plan that starts with conv_first, else NHWC (B,H,W,C).
+        intensity: x is the hologram INTENSITY; the first layer's loader takes the square root (inference plan only).
         Returns NHWC, or NCHW (B,2,H,W) planes when the plan ends with conv_last.
         While autograd is recording and the input or a parameter of the plan asks for a gradient, every step runs through its
         ``autograd`` Function (fp32 only): the backward pass of the training objective."""
@@ -222,12 +223,16 @@ class Plan:
                                                                 if m is not None for p in m.parameters())):
             if self.dtype != torch.float32:
                 raise NotImplementedError("the backward pass exists in fp32 only: set_compute_dtype(torch.float32) for training")
+            if intensity:
+                raise NotImplementedError("intensity input is an inference-plan option: pass the amplitude while autograd records")
             from . import autograd as _ag
             for st in self.steps:
                 x = _ag.run_step(st, x)
             return x
+        if intensity and not (self.steps and self.steps[0].kind == "first"):
+            raise RuntimeError("intensity input needs a plan that starts with the first encoder layer")
         for idx in range(len(self.steps)):
-            x = self.run_step(idx, x)
+            x = self.run_step(idx, x, intensity and idx == 0)
         return x
 
 
@@ -285,11 +290,11 @@ class HoloSequential(nn.Sequential):
         """NHWC in (or NCHW single-channel planes for a plan starting at vgg[0]) -> plan output."""
         return self._plan().run(x)
 
-    def forward(self, input):
+    def forward(self, input, intensity=False):
         if not input.is_cuda:
             raise RuntimeError("this network runs on MI355X HIP kernels only: move the input to a ROCm device "
                                "(the CPU restatement lives in oracle/ and is test infrastructure)")
         plan = self._plan()
         x = input if plan.steps and plan.steps[0].kind == "first" else ops.to_nhwc(input)
-        y = plan.run(x)
+        y = plan.run(x, intensity)
         return y if plan.ends_in_planes else ops.as_nchw_view(y)

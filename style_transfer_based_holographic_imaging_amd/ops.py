@@ -250,14 +250,15 @@ def pack_convt2x2(w_iohw: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # convolutions (activation dtype float32 or bfloat16 selects the _f32 / _bf16 entry point)
 # ---------------------------------------------------------------------------------------------
-def conv_first(x: torch.Tensor, w0, b0, w1, b1, out_dtype=torch.float32) -> torch.Tensor:
-    """vgg[0:4] (net.py:77-80): (B,1,H,W) -> NHWC (B,H,W,64)."""
+def conv_first(x: torch.Tensor, w0, b0, w1, b1, out_dtype=torch.float32, sqrt_input: bool = False) -> torch.Tensor:
+    """vgg[0:4] (net.py:77-80): (B,1,H,W) -> NHWC (B,H,W,64).  sqrt_input: x is the hologram intensity and the loader takes its
+    square root (test_field_retrieval_mnist.py:119 folded in; bit-identical to torch.sqrt first)."""
     _req(x, w0, b0, w1, b1)
     b, c, h, w = x.shape
     assert c == 1 and tuple(w0.shape) == (3, 1, 1, 1) and tuple(w1.shape) == (64, 3, 3, 3)
     x = _f32c(x)
     y = torch.empty((b, h, w, 64), dtype=out_dtype, device=x.device)
-    name = "holo_conv_first_" + _sfx(y)
+    name = ("holo_conv_first_sqrt_" if sqrt_input else "holo_conv_first_") + _sfx(y)
     w0c, b0c, w1c, b1c = (_f32c(t.detach()) for t in (w0, b0, w1, b1))
     _launch(name, lambda: getattr(lib, name)(x.data_ptr(), w0c.data_ptr(), b0c.data_ptr(), w1c.data_ptr(), b1c.data_ptr(),
                                              y.data_ptr(), b, h, w, _stream()),

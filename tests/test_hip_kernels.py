@@ -79,6 +79,19 @@ def test_conv_first(ops, dev, b, h, w):
     ref = F.relu(F.conv2d(F.pad(F.conv2d(x, w0, b0), (1, 1, 1, 1), mode="reflect"), w1, b1))
     y = ops.conv_first(x.to(dev), w0.to(dev), b0.to(dev), w1.to(dev), b1.to(dev))
     assert rel_err(ops.as_nchw_view(y).cpu(), ref) < 2e-6
+    # intensity in, square root in the loader (test_field_retrieval_mnist.py:119 folded in): the bits of the correctly rounded root first
+    # (torch.sqrt on the device gives the same; torch's vectorised HOST sqrt is an ulp off on ~16 % of values), for every
+    # activation format (batches of 16 take the bf16 matrix-core form of the layer)
+    inten = (x * x * 3.7).to(dev)
+    for dt, nb in ((torch.float32, 1), (torch.bfloat16, 1), (torch.bfloat16, 16), ("f32s", 1)):
+        xi = inten.repeat(nb, 1, 1, 1)
+        args = (w0.to(dev), b0.to(dev), w1.to(dev), b1.to(dev))
+        if dt == "f32s":
+            dt = ops.compute_dtype("f32s")
+        a = ops.conv_first(torch.sqrt(xi.double()).float(), *args, out_dtype=dt)      # the correctly rounded root (= torch.sqrt on the device)
+        f = ops.conv_first(xi, *args, out_dtype=dt, sqrt_input=True)
+        assert a.dtype == f.dtype and torch.equal(a.view(torch.int16 if a.element_size() == 2 else torch.int32),
+                                                   f.view(torch.int16 if f.element_size() == 2 else torch.int32))
 
 
 @pytest.mark.parametrize("b,h,w", [(2, 16, 16), (1, 19, 35), (2, 2, 2), (1, 64, 64)])

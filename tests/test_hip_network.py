@@ -327,6 +327,23 @@ def test_module_plumbing_matches_reference_usage(env, mnist_style):
         network.decoder[37].bias.data -= 1.0
 
 
+def test_intensity_input_takes_the_square_root_in_the_first_layer(env, mnist_style):
+    """field_retrieval(..., intensity=True) on the hologram intensity = field_retrieval on its correctly rounded square root
+    (test_field_retrieval_mnist.py:119 folded into the first layer's loader), bit for bit; recording autograd
+    refuses it."""
+    from utils.functions import field_retrieval
+    dev, network = env["dev"], env["net"]
+    g = torch.Generator().manual_seed(77)
+    inten = (torch.rand(3, 1, 64, 64, generator=g) * 2.0).to(dev)
+    sv = mnist_style.to(dev)
+    with torch.no_grad():
+        a0, p0, d0 = field_retrieval(network, torch.sqrt(inten.double()).float(), sv, 1.0, True)    # the correctly rounded root (torch.sqrt on the device gives the same)
+        a1, p1, d1 = field_retrieval(network, inten, sv, 1.0, True, intensity=True)
+    assert torch.equal(a0, a1) and torch.equal(p0, p1) and torch.equal(d0, d1)
+    with pytest.raises(NotImplementedError):
+        network.enc_1(inten.clone().requires_grad_(), intensity=True)
+
+
 def test_net_forward_values_against_reference_golden(env, golden):
     """Net.forward (net.py:199-226), forward values: content / style losses, generated amplitude and phase,
     style reconstruction and both predicted distances against the reference's own outputs, for every return form."""

@@ -4,12 +4,15 @@ inference path."""
 import torch
 
 
-def field_retrieval(network, content, style_vector, alpha=1.0, unkonwn_distance=False):
-    """(amplitude, phase[, distance (B,1,1,1)]) — the reference's keyword is misspelt and kept as is."""
+def field_retrieval(network, content, style_vector, alpha=1.0, unkonwn_distance=False, intensity=False):
+    """(amplitude, phase[, distance (B,1,1,1)]) — the reference's keyword is misspelt and kept as is.
+    ``intensity`` (additive, default off): ``content`` is the hologram intensity; its square root
+    (test_field_retrieval_mnist.py:119) is taken by the first layer's loader."""
     assert (0.0 <= alpha <= 1.0)
+    extra = {"intensity": True} if intensity else {}
     if not unkonwn_distance:
-        return network.field_retrieval(content, style_vector, alpha)
-    amplitude, phase, dist = network.field_retrieval(content, style_vector, alpha, unkonwn_distance)
+        return network.field_retrieval(content, style_vector, alpha, **extra)
+    amplitude, phase, dist = network.field_retrieval(content, style_vector, alpha, unkonwn_distance, **extra)
     return amplitude, phase, dist.view(-1, 1, 1, 1)
 
 

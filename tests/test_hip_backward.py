@@ -56,6 +56,26 @@ def test_conv_step(ag, dev, b, h, w, cin, cout, relu, pool):
     assert rel_err(bd.grad.cpu(), br.grad) < 2e-5
 
 
+def test_conv_step_accuracy_against_float64(ag, dev):
+    """a mid-size layer (2 x 128 -> 128 channels at 48 x 64, ReLU + pool) against float64 autograd: how close the fp32 MFMA
+    gradients are to the truth, not to another fp32 summation order (the LDS-staged weight gradient sums 6144 pixels per entry)"""
+    g = torch.Generator().manual_seed(64)
+    b, cin, cout, h, w = 2, 128, 128, 48, 64
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    bias = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), bias.double().requires_grad_()
+    y = F.max_pool2d(F.relu(F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr, br)), 2, 2, 0, ceil_mode=True)
+    up = torch.randn(y.shape, generator=g)
+    (y * up.double()).sum().backward()
+    xd, wd, bd = _nhwc(x, dev).requires_grad_(), wt.to(dev).requires_grad_(), bias.to(dev).requires_grad_()
+    yd = ag.ConvStep.apply(xd, wd, bd, True, True)
+    (yd * _nhwc(up, dev)).sum().backward()
+    errs = (rel_err(xd.grad.permute(0, 3, 1, 2).cpu(), xr.grad), rel_err(wd.grad.cpu(), wr.grad), rel_err(bd.grad.cpu(), br.grad))
+    print("relative error against float64 (dx, dw, db): %.1e %.1e %.1e" % errs)
+    assert max(errs) < 3e-6
+
+
 @pytest.mark.parametrize("gx,b,h,w,cin,cout,pool", [(2, 4, 6, 32, 64, 64, False), (3, 5, 9, 10, 64, 128, True), (4, 4, 8, 32, 128, 64, False),
                                                     (2, 3, 33, 64, 64, 64, True)])
 def test_conv_step_in_a_mosaic(ag, dev, monkeypatch, gx, b, h, w, cin, cout, pool):
